@@ -1,0 +1,82 @@
+"""ctypes binding of libgsrast.so (the C ABI declared in include/gsrast.h).
+
+The product path has NO fallback: if the library is missing or fails to load,
+every op raises. Pointers are passed as integers (`tensor.data_ptr()`), the
+stream as `torch.cuda.current_stream().cuda_stream`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libgsrast.so"
+_lock = threading.Lock()
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+
+# name -> argtypes; every function returns int except the three below.
+SIGNATURES = {
+    "gsr_project_fwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i,
+                        _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "gsr_project_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p, _p,
+                        _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+    "gsr_isect_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p],
+    "gsr_isect_scan": [_i, _p, _p, _p],
+    "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
+    "gsr_tile_sort": [_i, _p, _p, _p, _p, _p],
+    "gsr_rasterize_fwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
+                          _p, _p],
+    "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
+                          _p, _p, _i, _p, _p],
+}
+OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)
+
+
+class GsrastError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libgsrast.so once; raise GsrastError loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not _LIB_PATH.exists():
+            raise GsrastError(
+                f"{_LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback."
+            )
+        lib = C.CDLL(str(_LIB_PATH))
+        lib.gsr_last_error.restype = C.c_char_p
+        lib.gsr_arch.restype = C.c_char_p
+        lib.gsr_version.restype = C.c_int
+        for name, args in {**SIGNATURES, **OPTIONAL_SIGNATURES}.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise GsrastError(f"{name} failed ({rc}): {lib.gsr_last_error().decode()}")
+
+
+def ptr(t) -> int | None:
+    """data_ptr of a tensor or None."""
+    return None if t is None else t.data_ptr()

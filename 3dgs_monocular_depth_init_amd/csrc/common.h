@@ -1,0 +1,91 @@
+// common.h -- shared host/device helpers for libgsrast (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gsrast.h"
+
+namespace gsr {
+
+void set_error(const char *fmt, ...);
+
+#define GSR_REQUIRE(cond, ...)         \
+  do {                                 \
+    if (!(cond)) {                     \
+      gsr::set_error(__VA_ARGS__);     \
+      return GSR_EINVAL;               \
+    }                                  \
+  } while (0)
+
+#define GSR_CHECK_LAUNCH(name)                                                     \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      gsr::set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+      return GSR_EHIP;                                                             \
+    }                                                                              \
+  } while (0)
+
+#define GSR_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess) {                                                       \
+      gsr::set_error("%s failed: %s", #expr, hipGetErrorString(e__));              \
+      return GSR_EHIP;                                                             \
+    }                                                                              \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an
+// XCD and its L2). Remap so that every XCD walks one contiguous range of
+// work items: neighbouring tiles (which share Gaussians) then hit the same L2.
+// Speed only; any placement is correct. grid must be xcd_grid(n).
+static inline int xcd_grid(int n) { return ceil_div(n, 8) * 8; }
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  int per = (n + 7) >> 3;
+  return (b & 7) * per + (b >> 3);
+}
+
+#if defined(__HIPCC__)
+// ---- wave64 reductions on DPP (no LDS traffic) ------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+// Sum over the 64 lanes; the total is valid in lane 63 (and returned
+// wave-uniformly through readlane).
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xb1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4e>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x124>(v);   // row_ror:4
+  v = dpp_add<0x128>(v);   // row_ror:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+#endif
+
+}  // namespace gsr

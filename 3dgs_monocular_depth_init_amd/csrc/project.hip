@@ -1,0 +1,247 @@
+// project.hip -- A3 + A4: EWA projection fused with SH colour evaluation, and
+// the fused backward (raster gradient rows -> parameter gradients).
+//
+// Replaces the projection / spherical-harmonics stages that
+// gsplat.rendering.rasterization runs for gs_init_compare/runner.py:341 and
+// their backward under loss.backward() (runner.py:547).
+//
+// HBM-bound stages: one thread per (camera, Gaussian) forward; one thread per
+// Gaussian backward (cameras summed in registers, so no atomics and every
+// output is written exactly once).
+#include "common.h"
+#include "gs_math.h"
+
+namespace gsr {
+
+__global__ void __launch_bounds__(256)
+project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+                   const float *__restrict__ scales, const float *__restrict__ opacities,
+                   const float *__restrict__ viewmats, const float *__restrict__ Ks,
+                   const float *__restrict__ campos, int width, int height, float eps2d,
+                   float near_plane, float far_plane, float radius_clip, int calc_comp,
+                   int sh_degree, const float *__restrict__ sh0, int sh0_stride,
+                   const float *__restrict__ shN, int shN_stride, int32_t *__restrict__ radii,
+                   float *__restrict__ means2d, float *__restrict__ depths,
+                   float *__restrict__ conics, float *__restrict__ compensations,
+                   float *__restrict__ colors_out, int color_stride, int depth_channel) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)C * N) return;
+  int c = (int)(g / N);
+  int i = (int)(g - (int64_t)c * N);
+  gs::Camera cam = gs::load_camera(viewmats + c * 16, Ks + c * 9);
+  float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
+  float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
+  float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+  float opac = opacities ? opacities[i] : -1.f;
+  gs::Mat3 covar = gs::quat_scale_to_covar(q, s);
+  gs::Proj p = gs::project_ewa(cam, mean, covar, opac, width, height, eps2d, near_plane,
+                               far_plane, radius_clip, calc_comp != 0);
+  radii[g * 2 + 0] = p.rx;
+  radii[g * 2 + 1] = p.ry;
+  means2d[g * 2 + 0] = p.mx;
+  means2d[g * 2 + 1] = p.my;
+  depths[g] = p.depth;
+  conics[g * 3 + 0] = p.ca;
+  conics[g * 3 + 1] = p.cb;
+  conics[g * 3 + 2] = p.cc;
+  if (compensations) compensations[g] = p.comp;
+  if (!colors_out) return;
+  float *co = colors_out + g * color_stride;
+  if (sh_degree >= 0) {
+    float r = 0.f, gg = 0.f, b = 0.f;
+    if (p.rx > 0) {
+      float dx = mean[0] - campos[c * 3 + 0];
+      float dy = mean[1] - campos[c * 3 + 1];
+      float dz = mean[2] - campos[c * 3 + 2];
+      float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
+      const float *c0 = sh0 + (int64_t)i * sh0_stride;
+      const float *cn = shN + (int64_t)i * shN_stride;
+      gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
+                   [&](int k, float bk, float, float, float) {
+                     const float *ck = (k == 0) ? c0 : cn + (k - 1) * 3;
+                     r += bk * ck[0];
+                     gg += bk * ck[1];
+                     b += bk * ck[2];
+                   });
+    }
+    co[0] = fmaxf(r + 0.5f, 0.f);
+    co[1] = fmaxf(gg + 0.5f, 0.f);
+    co[2] = fmaxf(b + 0.5f, 0.f);
+  }
+  if (depth_channel >= 0) co[depth_channel] = p.depth;
+}
+
+// One thread per Gaussian; loops over cameras.
+__global__ void __launch_bounds__(256, 2)
+project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+                   const float *__restrict__ scales, const float *__restrict__ viewmats,
+                   const float *__restrict__ Ks, const float *__restrict__ campos, int width,
+                   int height, float eps2d, int sh_degree, const float *__restrict__ sh0,
+                   int sh0_stride, const float *__restrict__ shN, int shN_stride,
+                   const int32_t *__restrict__ radii, const float *__restrict__ grad_rows,
+                   const float *__restrict__ v_depths, const float *__restrict__ v_comps,
+                   int depth_channel, float *__restrict__ v_means, float *__restrict__ v_quats,
+                   float *__restrict__ v_scales, float *__restrict__ v_sh0, int v_sh0_stride,
+                   float *__restrict__ v_shN, int v_shN_stride, int sh_K) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
+  float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
+  float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+  gs::Mat3 covar = gs::quat_scale_to_covar(q, s);
+  float v_mean[3] = {0.f, 0.f, 0.f};
+  gs::Mat3 v_covar = gs::mat3_zero();
+  float v_coef[16][3];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v_coef[k][0] = v_coef[k][1] = v_coef[k][2] = 0.f;
+
+  for (int c = 0; c < C; ++c) {
+    int64_t g = (int64_t)c * N + i;
+    if (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) continue;
+    const float *row = grad_rows + g * GSR_GRAD_ROW;
+    float v_m2d[2] = {row[GSR_GR_MEAN2D], row[GSR_GR_MEAN2D + 1]};
+    float v_con[3] = {row[GSR_GR_CONIC], row[GSR_GR_CONIC + 1], row[GSR_GR_CONIC + 2]};
+    float v_depth = 0.f;
+    if (v_depths) v_depth += v_depths[g];
+    if (depth_channel >= 0) v_depth += row[GSR_GR_COLOR + depth_channel];
+    float v_comp = v_comps ? v_comps[g] : 0.f;
+    gs::Camera cam = gs::load_camera(viewmats + c * 16, Ks + c * 9);
+    gs::project_ewa_vjp(cam, mean, covar, width, height, eps2d, v_m2d, v_depth, v_con, v_comp,
+                        v_mean, v_covar);
+    if (sh_degree >= 0) {
+      float v_col[3] = {row[GSR_GR_COLOR], row[GSR_GR_COLOR + 1], row[GSR_GR_COLOR + 2]};
+      float dx = mean[0] - campos[c * 3 + 0];
+      float dy = mean[1] - campos[c * 3 + 1];
+      float dz = mean[2] - campos[c * 3 + 2];
+      float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
+      float inv = 1.0f / nrm;
+      float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+      const float *c0 = sh0 + (int64_t)i * sh0_stride;
+      const float *cn = shN + (int64_t)i * shN_stride;
+      // pass 1: pre-clamp colour, for the clamp_min(., 0) mask
+      float col[3] = {0.f, 0.f, 0.f};
+      gs::sh_visit(sh_degree, ux, uy, uz, [&](int k, float b, float, float, float) {
+        const float *ck = (k == 0) ? c0 : cn + (k - 1) * 3;
+        col[0] += b * ck[0];
+        col[1] += b * ck[1];
+        col[2] += b * ck[2];
+      });
+      for (int ch = 0; ch < 3; ++ch)
+        if (col[ch] + 0.5f < 0.f) v_col[ch] = 0.f;
+      // pass 2: coefficient and direction gradients, one coefficient at a time
+      float vx = 0.f, vy = 0.f, vz = 0.f;
+      gs::sh_visit(sh_degree, ux, uy, uz, [&](int k, float b, float bx, float by, float bz) {
+        const float *ck = (k == 0) ? c0 : cn + (k - 1) * 3;
+        const float dotc = ck[0] * v_col[0] + ck[1] * v_col[1] + ck[2] * v_col[2];
+        vx += bx * dotc;
+        vy += by * dotc;
+        vz += bz * dotc;
+        v_coef[k][0] += b * v_col[0];
+        v_coef[k][1] += b * v_col[1];
+        v_coef[k][2] += b * v_col[2];
+      });
+      // through dir / |dir|
+      float dot = vx * ux + vy * uy + vz * uz;
+      v_mean[0] += (vx - dot * ux) * inv;
+      v_mean[1] += (vy - dot * uy) * inv;
+      v_mean[2] += (vz - dot * uz) * inv;
+    }
+  }
+  float v_q[4], v_s[3];
+  gs::quat_scale_to_covar_vjp(q, s, v_covar, v_q, v_s);
+  v_means[i * 3 + 0] = v_mean[0];
+  v_means[i * 3 + 1] = v_mean[1];
+  v_means[i * 3 + 2] = v_mean[2];
+  v_quats[i * 4 + 0] = v_q[0];
+  v_quats[i * 4 + 1] = v_q[1];
+  v_quats[i * 4 + 2] = v_q[2];
+  v_quats[i * 4 + 3] = v_q[3];
+  v_scales[i * 3 + 0] = v_s[0];
+  v_scales[i * 3 + 1] = v_s[1];
+  v_scales[i * 3 + 2] = v_s[2];
+  if (v_sh0) {
+    float *o0 = v_sh0 + (int64_t)i * v_sh0_stride;
+    o0[0] = v_coef[0][0];
+    o0[1] = v_coef[0][1];
+    o0[2] = v_coef[0][2];
+    float *on = v_shN + (int64_t)i * v_shN_stride;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      if (k < sh_K) {
+        on[(k - 1) * 3 + 0] = v_coef[k][0];
+        on[(k - 1) * 3 + 1] = v_coef[k][1];
+        on[(k - 1) * 3 + 2] = v_coef[k][2];
+      }
+    }
+  }
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *quats,
+                               const float *scales, const float *opacities,
+                               const float *viewmats, const float *Ks, const float *campos,
+                               int width, int height, float eps2d, float near_plane,
+                               float far_plane, float radius_clip, int calc_compensations,
+                               int sh_degree, const float *sh0, int sh0_stride, const float *shN,
+                               int shN_stride, int32_t *radii, float *means2d, float *depths,
+                               float *conics, float *compensations, float *colors_out,
+                               int color_stride, int depth_channel, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "project_fwd: bad sizes C=%d N=%d %dx%d",
+              C, N, width, height);
+  if ((int64_t)C * N == 0) return GSR_OK;
+  GSR_REQUIRE(means && quats && scales && viewmats && Ks && radii && means2d && depths && conics,
+              "project_fwd: null pointer");
+  GSR_REQUIRE(sh_degree <= 3, "project_fwd: sh_degree %d > 3", sh_degree);
+  if (sh_degree >= 0) {
+    GSR_REQUIRE(colors_out && sh0 && campos && (sh_degree == 0 || shN),
+                "project_fwd: SH requested without sh0/shN/campos/colors_out");
+    GSR_REQUIRE(color_stride >= 3, "project_fwd: color_stride %d < 3", color_stride);
+  }
+  if (colors_out)
+    GSR_REQUIRE(depth_channel < color_stride, "project_fwd: depth_channel %d >= stride %d",
+                depth_channel, color_stride);
+  int64_t total = (int64_t)C * N;
+  GSR_REQUIRE(total / 256 + 1 < 2147483647LL, "project_fwd: C*N too large");
+  dim3 grid((unsigned)gsr::ceil_div64(total, 256));
+  hipLaunchKernelGGL(gsr::project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
+                     quats, scales, opacities, viewmats, Ks, campos, width, height, eps2d,
+                     near_plane, far_plane, radius_clip, calc_compensations, sh_degree, sh0,
+                     sh0_stride, shN, shN_stride, radii, means2d, depths, conics, compensations,
+                     colors_out, color_stride, colors_out ? depth_channel : -1);
+  GSR_CHECK_LAUNCH("project_fwd");
+  return GSR_OK;
+}
+
+extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *quats,
+                               const float *scales, const float *viewmats, const float *Ks,
+                               const float *campos, int width, int height, float eps2d,
+                               int sh_degree, const float *sh0, int sh0_stride, const float *shN,
+                               int shN_stride, const int32_t *radii, const float *conics,
+                               const float *compensations, const float *grad_rows,
+                               const float *v_depths, const float *v_compensations,
+                               int depth_channel, float *v_means, float *v_quats,
+                               float *v_scales, float *v_sh0, int v_sh0_stride, float *v_shN,
+                               int v_shN_stride, int sh_K, void *stream) {
+  (void)conics;
+  (void)compensations;
+  GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd: bad sizes");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(means && quats && scales && viewmats && Ks && radii && grad_rows && v_means &&
+                  v_quats && v_scales,
+              "project_bwd: null pointer");
+  GSR_REQUIRE(sh_degree <= 3 && sh_K <= 16, "project_bwd: sh_degree/sh_K out of range");
+  if (sh_degree >= 0)
+    GSR_REQUIRE(sh0 && campos && v_sh0 && (sh_K == 1 || (shN && v_shN)) &&
+                    (sh_degree + 1) * (sh_degree + 1) <= sh_K,
+                "project_bwd: SH arguments inconsistent");
+  GSR_REQUIRE(depth_channel < 5, "project_bwd: depth_channel out of range");
+  dim3 grid((unsigned)gsr::ceil_div(N, 256));
+  hipLaunchKernelGGL(gsr::project_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
+                     quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree, sh0,
+                     sh0_stride, shN, shN_stride, radii, grad_rows, v_depths, v_compensations,
+                     depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
+                     v_sh0_stride, v_shN, v_shN_stride, sh_K);
+  GSR_CHECK_LAUNCH("project_bwd");
+  return GSR_OK;
+}

@@ -1,0 +1,420 @@
+"""`rasterization()` -- the operator boundary of the hot path.
+
+Drop-in for the third-party call the reference makes at
+/root/reference/gs_init_compare/runner.py:341-362
+(`gsplat.rendering.rasterization`, gsplat==1.5.2 pinned at setup.py:15), with
+the same keyword names, argument meaning, return triple
+`(render_colors [C,H,W,D], render_alphas [C,H,W,1], meta)` and the `meta`
+entries the reference's callers consume (runner.py:497-503, 639-647, 663:
+`means2d` as an autograd intermediate that accepts `.retain_grad()`,
+`radii`, `width`, `height`, `n_cameras`, `gaussian_ids`).
+
+All arithmetic runs in hand-written HIP kernels (libgsrast.so, C ABI in
+include/gsrast.h). PyTorch only owns memory, the stream and the autograd
+graph. There is no CPU / eager fallback: tensors must live on a ROCm device
+and the library must be built, otherwise the call raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import call, ptr
+
+TILE = 16
+GRAD_ROW = 16
+GR_MEAN2D, GR_CONIC, GR_OPAC, GR_COLOR, GR_ABS = 0, 2, 5, 6, 12
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_cuda(*tensors: Optional[Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.GsrastError(
+                "rasterization(): tensors must be on a ROCm device; this build has no CPU path"
+            )
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# A3 + A4: projection fused with SH evaluation
+# --------------------------------------------------------------------------- #
+class _ProjectSH(torch.autograd.Function):
+    """(means, quats, scales, sh) -> (radii, means2d, depths, conics, comps, colors).
+
+    sh_a / sh_b: either (colors [N,K,3], None) -- gsplat's concatenated layout --
+    or (sh0 [N,1,3], shN [N,K-1,3]) -- the reference's own parameter layout
+    (runner.py:112-115), which avoids the torch.cat of runner.py:338.
+    """
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg):
+        (width, height, eps2d, near, far, radius_clip, calc_comp, sh_degree, color_stride,
+         depth_channel) = cfg
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty(C, N, 2, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_comp else None
+        colors = None
+        sh0_ptr = shN_ptr = None
+        sh0_stride = shN_stride = 0
+        if sh_degree >= 0:
+            colors = torch.empty(C, N, color_stride, dtype=torch.float32, device=dev)
+            if sh_b is None:
+                K = sh_a.shape[1]
+                sh0_ptr, shN_ptr = sh_a.data_ptr(), sh_a.data_ptr() + 12
+                sh0_stride = shN_stride = 3 * K
+            else:
+                K = 1 + sh_b.shape[1]
+                sh0_ptr, shN_ptr = sh_a.data_ptr(), sh_b.data_ptr()
+                sh0_stride, shN_stride = 3, 3 * (K - 1)
+            if (sh_degree + 1) ** 2 > K:
+                raise ValueError(f"sh_degree {sh_degree} needs {(sh_degree + 1) ** 2} coefficients, got {K}")
+        call("gsr_project_fwd", C, N, ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+             ptr(viewmats), ptr(Ks), ptr(campos), width, height, eps2d, near, far, radius_clip,
+             int(calc_comp), sh_degree, sh0_ptr, sh0_stride, shN_ptr, shN_stride, ptr(radii),
+             ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(colors), color_stride,
+             depth_channel, _stream())
+        ctx.cfg = cfg
+        ctx.split = sh_b is not None
+        ctx.save_for_backward(means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        if comps is None:
+            comps = torch.empty(0, device=dev)
+        if colors is None:
+            colors = torch.empty(0, device=dev)
+        return radii, means2d, depths, conics, comps, colors
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_colors):
+        (width, height, eps2d, near, far, radius_clip, calc_comp, sh_degree, color_stride,
+         depth_channel) = ctx.cfg
+        means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii = ctx.saved_tensors
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        rows = _rows_from_grads(C, N, v_means2d, v_conics, v_colors if sh_degree >= 0 else None,
+                                color_stride)
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_sh_a = v_sh_b = None
+        v_sh0_ptr = v_shN_ptr = None
+        sh0_ptr = shN_ptr = None
+        sh0_stride = shN_stride = v0_stride = vN_stride = 0
+        K = 0
+        if sh_degree >= 0:
+            if not ctx.split:
+                K = sh_a.shape[1]
+                v_sh_a = torch.empty_like(sh_a)
+                sh0_ptr, shN_ptr = sh_a.data_ptr(), sh_a.data_ptr() + 12
+                v_sh0_ptr, v_shN_ptr = v_sh_a.data_ptr(), v_sh_a.data_ptr() + 12
+                sh0_stride = shN_stride = v0_stride = vN_stride = 3 * K
+            else:
+                K = 1 + sh_b.shape[1]
+                v_sh_a, v_sh_b = torch.empty_like(sh_a), torch.empty_like(sh_b)
+                sh0_ptr, shN_ptr = sh_a.data_ptr(), sh_b.data_ptr()
+                v_sh0_ptr, v_shN_ptr = v_sh_a.data_ptr(), v_sh_b.data_ptr()
+                sh0_stride, shN_stride = 3, 3 * (K - 1)
+                v0_stride, vN_stride = 3, 3 * (K - 1)
+        if v_depths is not None:
+            v_depths = _f32c(v_depths)
+        if v_comps is not None and calc_comp:
+            v_comps = _f32c(v_comps)
+        else:
+            v_comps = None
+        call("gsr_project_bwd", C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+             ptr(campos), width, height, eps2d, sh_degree, sh0_ptr, sh0_stride, shN_ptr,
+             shN_stride, ptr(radii), None, None, ptr(rows), ptr(v_depths), ptr(v_comps),
+             depth_channel if sh_degree >= 0 else -1, ptr(v_means), ptr(v_quats), ptr(v_scales),
+             v_sh0_ptr, v0_stride, v_shN_ptr, vN_stride, K, _stream())
+        return v_means, v_quats, v_scales, None, v_sh_a, v_sh_b, None, None, None, None
+
+
+def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride: int) -> Tensor:
+    """Return the [C*N,16] gradient-row buffer the projection backward reads.
+
+    Fast path: the incoming grads are the strided views _Rasterize.backward
+    returned over one row buffer -> reuse it, no copy. Otherwise (user-built
+    grads, hooks) pack them into a fresh buffer with torch ops on the device.
+    """
+    base = None
+    for v, off, width in ((v_means2d, GR_MEAN2D, 2), (v_conics, GR_CONIC, 3), (v_colors, GR_COLOR, None)):
+        if v is None:
+            continue
+        b = getattr(v, "_base", None)
+        ok = (
+            b is not None and b.dim() == 2 and b.shape == (C * N, GRAD_ROW) and b.is_contiguous()
+            and v.stride()[-1] == 1 and v.stride()[-2] == GRAD_ROW
+            and v.storage_offset() == b.storage_offset() + off
+            and (base is None or base is b)
+        )
+        if not ok:
+            base = None
+            break
+        base = b
+    else:
+        if base is not None:
+            return base
+    any_v = next((v for v in (v_means2d, v_conics, v_colors) if v is not None), None)
+    dev = any_v.device if any_v is not None else torch.device("cuda")
+    rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
+    if v_means2d is not None:
+        rows[:, GR_MEAN2D:GR_MEAN2D + 2] = v_means2d.reshape(C * N, 2)
+    if v_conics is not None:
+        rows[:, GR_CONIC:GR_CONIC + 3] = v_conics.reshape(C * N, 3)
+    if v_colors is not None:
+        w = v_colors.shape[-1]
+        rows[:, GR_COLOR:GR_COLOR + w] = v_colors.reshape(C * N, w)
+    return rows
+
+
+# --------------------------------------------------------------------------- #
+# A5: tile intersection lists (not differentiable)
+# --------------------------------------------------------------------------- #
+@torch.no_grad()
+def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
+                       want_tiles_per_gauss: bool = False):
+    """Returns (tile_offsets [n_tiles+1] int32, flatten_ids [I] int32,
+    isect_keys [I] int64 (depth_bits<<32 | g, sorted per tile), tiles_per_gauss or None)."""
+    C, N = depths.shape
+    dev = depths.device
+    n_tiles = C * tile_w * tile_h
+    tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    tpg = torch.empty(C, N, dtype=torch.int32, device=dev) if want_tiles_per_gauss else None
+    st = _stream()
+    call("gsr_isect_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(tpg),
+         ptr(tile_counts), st)
+    call("gsr_isect_scan", n_tiles, ptr(tile_counts), ptr(tile_offsets), st)
+    n_isects = int(tile_offsets[-1].item())          # the one host sync of the step
+    keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    if n_isects > 0:
+        call("gsr_isect_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
+             ptr(tile_offsets), ptr(tile_counts), ptr(keys), n_isects, st)
+        big_list = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+        call("gsr_tile_sort", n_tiles, ptr(tile_offsets), ptr(keys), ptr(flatten_ids),
+             ptr(big_list), st)
+    return tile_offsets, flatten_ids[:n_isects], keys[:n_isects], tpg
+
+
+# --------------------------------------------------------------------------- #
+# A6 / A7: compositing
+# --------------------------------------------------------------------------- #
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, flatten_ids,
+                cfg):
+        width, height, tile_w, tile_h, CH, absgrad = cfg
+        C, N = means2d.shape[0], means2d.shape[1]
+        dev = means2d.device
+        color_stride = colors.shape[-1]
+        render_colors = torch.empty(C, height, width, CH, dtype=torch.float32, device=dev)
+        render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        per_cam = int(opacities.dim() == 2)
+        call("gsr_rasterize_fwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
+             ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
+             ptr(tile_offsets), ptr(flatten_ids), ptr(render_colors), ptr(render_alphas),
+             ptr(last_ids), _stream())
+        ctx.cfg = cfg
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, tile_offsets,
+                              flatten_ids, render_alphas, last_ids)
+        ctx.mark_non_differentiable(last_ids)
+        return render_colors, render_alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas, _v_last):
+        width, height, tile_w, tile_h, CH, absgrad = ctx.cfg
+        (means2d, conics, colors, opacities, backgrounds, tile_offsets, flatten_ids,
+         render_alphas, last_ids) = ctx.saved_tensors
+        C, N = means2d.shape[0], means2d.shape[1]
+        dev = means2d.device
+        color_stride = colors.shape[-1]
+        if v_render_colors is None:
+            v_render_colors = torch.zeros(C, height, width, CH, dtype=torch.float32, device=dev)
+        if v_render_alphas is None:
+            v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
+        v_render_colors = _f32c(v_render_colors)
+        v_render_alphas = _f32c(v_render_alphas)
+        rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
+        per_cam = int(opacities.dim() == 2)
+        call("gsr_rasterize_bwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
+             ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
+             ptr(tile_offsets), ptr(flatten_ids), ptr(render_alphas), ptr(last_ids),
+             ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows), _stream())
+        v_means2d = rows[:, GR_MEAN2D:GR_MEAN2D + 2].view(C, N, 2)
+        v_conics = rows[:, GR_CONIC:GR_CONIC + 3].view(C, N, 3)
+        v_colors = rows[:, GR_COLOR:GR_COLOR + color_stride].view(C, N, color_stride)
+        v_opac = rows[:, GR_OPAC].view(C, N)
+        if not per_cam:
+            v_opac = v_opac.sum(0) if C > 1 else v_opac.reshape(N)
+        if absgrad:
+            means2d.absgrad = rows[:, GR_ABS:GR_ABS + 2].view(C, N, 2)
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            T_final = 1.0 - render_alphas
+            v_bg = (v_render_colors * T_final).sum(dim=(1, 2))
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# the boundary
+# --------------------------------------------------------------------------- #
+def rasterization(
+    means: Tensor,                 # [N,3]
+    quats: Tensor,                 # [N,4] wxyz, un-normalised is fine
+    scales: Tensor,                # [N,3] (already exp-activated)
+    opacities: Tensor,             # [N]   (already sigmoid-activated)
+    colors,                        # [N,K,3] SH | [N,D] | [C,N,D] | (sh0, shN) tuple
+    viewmats: Tensor,              # [C,4,4] world->camera
+    Ks: Tensor,                    # [C,3,3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = TILE,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: str = "pinhole",
+    covars: Optional[Tensor] = None,
+    **unsupported,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """See module docstring. `packed` only changes gsplat's intermediate
+    memory layout, never the rendered result: both values run the same dense
+    [C,N] kernels here (and `meta` keeps the dense layout), `sparse_grad`
+    (needs packed indices) is rejected."""
+    if unsupported:
+        raise TypeError(f"rasterization(): unsupported arguments {sorted(unsupported)}")
+    if camera_model != "pinhole":
+        raise NotImplementedError(f"camera_model={camera_model!r}: only 'pinhole' is built")
+    if covars is not None:
+        raise NotImplementedError("covars=: pass quats + scales")
+    if distributed:
+        raise NotImplementedError(
+            "distributed=True (gsplat's Gaussian-sharded all-to-all) is not built; use the "
+            "view-parallel replicas of `distributed.ViewParallel` and call with distributed=False"
+        )
+    if sparse_grad:
+        raise NotImplementedError("sparse_grad=True needs packed indices; not built")
+    if tile_size != TILE:
+        raise NotImplementedError(f"tile_size={tile_size}: kernels are built for {TILE}")
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise ValueError(f"render_mode={render_mode!r}")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"rasterize_mode={rasterize_mode!r}")
+    split_sh = isinstance(colors, (tuple, list))
+    _check_cuda(means, quats, scales, opacities, viewmats, Ks, backgrounds,
+                *(colors if split_sh else (colors,)))
+    _lib.load()
+
+    N, C = means.shape[0], viewmats.shape[0]
+    assert means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3), "shapes"
+    assert opacities.shape == (N,), f"opacities {tuple(opacities.shape)}"
+    assert viewmats.shape == (C, 4, 4) and Ks.shape == (C, 3, 3), "camera shapes"
+    means, quats, scales, opacities = _f32c(means), _f32c(quats), _f32c(scales), _f32c(opacities)
+    viewmats, Ks = _f32c(viewmats), _f32c(Ks)
+    antialiased = rasterize_mode == "antialiased"
+    with_depth = render_mode in ("RGB+D", "RGB+ED")
+    depth_only = render_mode in ("D", "ED")
+
+    use_sh = sh_degree is not None and not depth_only
+    sh_a = sh_b = None
+    if use_sh:
+        if split_sh:
+            sh_a, sh_b = _f32c(colors[0]), _f32c(colors[1])
+            assert sh_a.shape == (N, 1, 3) and sh_b.shape[0] == N and sh_b.shape[2] == 3
+        else:
+            assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3, (
+                "with sh_degree set, colors must be [N,K,3]")
+            sh_a = _f32c(colors)
+        color_stride = 4 if with_depth else 3
+        depth_channel = 3 if with_depth else -1
+        campos = torch.linalg.inv(viewmats)[:, :3, 3].contiguous()
+    else:
+        color_stride, depth_channel, campos = 0, -1, None
+
+    cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
+           float(radius_clip), bool(antialiased), int(sh_degree) if use_sh else -1, color_stride,
+           depth_channel)
+    radii, means2d, depths, conics, comps, sh_colors = _ProjectSH.apply(
+        means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg)
+
+    if antialiased:
+        opac = opacities[None, :] * comps              # [C,N]
+    else:
+        opac = opacities
+
+    if use_sh:
+        feats = sh_colors                                  # [C,N,3|4], depth already in ch 3
+        CH = color_stride
+    else:
+        if depth_only:
+            feats = depths[..., None]
+        else:
+            col = colors[0] if split_sh else colors
+            col = _f32c(col)
+            if col.dim() == 2:
+                col = col[None].expand(C, -1, -1)
+            assert col.shape[:2] == (C, N), f"colors {tuple(col.shape)}"
+            feats = torch.cat([col, depths[..., None]], dim=-1) if with_depth else col
+        feats = feats.contiguous()
+        CH = feats.shape[-1]
+        if CH > 5:
+            raise NotImplementedError(f"{CH} colour channels: kernels are built for <= 5")
+    if backgrounds is not None:
+        backgrounds = _f32c(backgrounds)
+        if with_depth:
+            backgrounds = torch.cat([backgrounds, torch.zeros_like(backgrounds[:, :1])], dim=-1)
+        elif depth_only:
+            backgrounds = torch.zeros(C, 1, dtype=torch.float32, device=means.device)
+        backgrounds = backgrounds.contiguous()
+
+    tile_w = math.ceil(width / TILE)
+    tile_h = math.ceil(height / TILE)
+    tile_offsets, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
+        means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False)
+
+    rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
+    render_colors, render_alphas, _last = _Rasterize.apply(
+        means2d, conics, feats, opac, backgrounds, tile_offsets, flatten_ids, rcfg)
+
+    if render_mode in ("ED", "RGB+ED"):
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)],
+            dim=-1)
+
+    meta = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+        "opacities": opac, "tile_width": tile_w, "tile_height": tile_h,
+        "tiles_per_gauss": tpg, "isect_ids": isect_keys, "flatten_ids": flatten_ids,
+        "isect_offsets": tile_offsets[:-1].view(C, tile_h, tile_w),
+        "width": width, "height": height, "tile_size": TILE, "n_cameras": C,
+    }
+    return render_colors, render_alphas, meta

@@ -1,0 +1,194 @@
+/*
+ * gsrast.h -- C ABI of libgsrast.so, the MI355X (gfx950) hot path of
+ * deivse/3dgs_monocular_depth_init.
+ *
+ * Every entry point takes raw DEVICE pointers, sizes, scalar parameters and a
+ * HIP stream (passed as void*; NULL = the null stream). Nothing here knows
+ * about torch. All functions are asynchronous on `stream`, allocate nothing
+ * (the caller owns every buffer, including scratch) and return 0 on success
+ * or a negative GSR_E* code; gsr_last_error() gives the message of the last
+ * failure on the calling thread.
+ *
+ * What each group replaces in the reference (paths under /root/reference):
+ *   - gsr_project_*, gsr_isect_*, gsr_tile_sort, gsr_rasterize_*:
+ *       the third-party call `gsplat.rendering.rasterization(...)` made at
+ *       gs_init_compare/runner.py:341-362 (again via rasterize_splats from
+ *       nerfbaselines_integration/method.py:754,829) and its autograd
+ *       backward triggered by `loss.backward()` at runner.py:547.
+ *   - gsr_lstsq_*, gsr_ransac_*:
+ *       gs_init_compare/depth_alignment/alignment/lstsqrs.py:9-54 and
+ *       gs_init_compare/depth_alignment/alignment/ransacs.py:100-189.
+ *   - gsr_subsample_*, gsr_sfm_patch_mask, gsr_unproject_*:
+ *       gs_init_compare/depth_subsampling/static_subsampler.py:8-22,
+ *       adaptive_subsampling.py:48-122, num_sfm_points_mask.py:7-64 and
+ *       gs_init_compare/depth_prediction/points_from_depth.py:111-180,270-312.
+ *
+ * Layout conventions: row-major, fp32 unless stated, indices int32.
+ *   N  = number of Gaussians, C = cameras in this batch, g = c*N + i is the
+ *   flat (camera, Gaussian) index, CH = colour channels composited (1..5).
+ */
+#ifndef GSRAST_H
+#define GSRAST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported value) */
+#define GSR_EHIP (-2)     /* a HIP runtime call or kernel launch failed              */
+#define GSR_ECAPACITY (-3)/* caller-provided buffer too small                         */
+
+#define GSR_TILE 16       /* tile edge in pixels (gsplat tile_size default)            */
+#define GSR_GRAD_ROW 16   /* floats per (camera,Gaussian) row of the gradient scratch  */
+/* gradient-row field offsets (floats): */
+#define GSR_GR_MEAN2D 0   /* 2: dL/d means2d (pixels)        */
+#define GSR_GR_CONIC 2    /* 3: dL/d conic (a,b,c)           */
+#define GSR_GR_OPAC 5     /* 1: dL/d opacity                 */
+#define GSR_GR_COLOR 6    /* CH (<=5): dL/d colour channels  */
+#define GSR_GR_ABS 12     /* 2: sum |dL/d means2d| (absgrad) */
+
+int gsr_version(void);
+const char *gsr_last_error(void);
+/* Name of the code-object architecture the library was built for ("gfx950"). */
+const char *gsr_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * A3 + A4: 3D->2D EWA projection fused with SH colour evaluation.
+ * One thread per (camera, Gaussian).
+ * sh0/shN may be NULL (no SH: colours are supplied by the caller elsewhere).
+ * sh0 points at coefficient 0 of Gaussian 0, consecutive Gaussians are
+ * sh0_stride floats apart; shN points at coefficient 1, shN_stride apart
+ * (a concatenated [N,K,3] tensor is sh0=p, shN=p+3, both strides 3K).
+ * colors_out is [C*N, color_stride]; RGB goes to channels 0..2 and, when
+ * depth_channel >= 0, the camera-space depth to that channel.
+ * --------------------------------------------------------------------------*/
+int gsr_project_fwd(int C, int N, const float *means, const float *quats, const float *scales,
+                    const float *opacities /* [N] or NULL */, const float *viewmats /* [C,4,4] */,
+                    const float *Ks /* [C,3,3] */, const float *campos /* [C,3] */, int width,
+                    int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                    int calc_compensations, int sh_degree /* -1: no SH */, const float *sh0,
+                    int sh0_stride, const float *shN, int shN_stride,
+                    int32_t *radii /* [C,N,2] */, float *means2d /* [C,N,2] */,
+                    float *depths /* [C,N] */, float *conics /* [C,N,3] */,
+                    float *compensations /* [C,N] or NULL */, float *colors_out /* or NULL */,
+                    int color_stride, int depth_channel, void *stream);
+
+/* Backward of gsr_project_fwd. grad_rows is the [C*N, GSR_GRAD_ROW] scratch
+ * filled by gsr_rasterize_bwd (fields GSR_GR_*). v_depths [C,N] may be NULL
+ * (then the depth gradient is taken from colour channel depth_channel if
+ * >= 0). v_compensations [C,N] may be NULL. Outputs are WRITTEN (not
+ * accumulated); camera contributions are summed inside the kernel. */
+int gsr_project_bwd(int C, int N, const float *means, const float *quats, const float *scales,
+                    const float *viewmats, const float *Ks, const float *campos, int width,
+                    int height, float eps2d, int sh_degree, const float *sh0, int sh0_stride,
+                    const float *shN, int shN_stride, const int32_t *radii, const float *conics,
+                    const float *compensations, const float *grad_rows, const float *v_depths,
+                    const float *v_compensations, int depth_channel, float *v_means /* [N,3] */,
+                    float *v_quats /* [N,4] */, float *v_scales /* [N,3] */,
+                    float *v_sh0 /* or NULL */, int v_sh0_stride, float *v_shN, int v_shN_stride,
+                    int sh_K /* coefficients stored per Gaussian */, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * A5: per-tile depth-sorted intersection lists.
+ * tile ids are c*tile_h*tile_w + ty*tile_w + tx; n_tiles = C*tile_h*tile_w.
+ * gsr_isect_count : tile_counts[n_tiles] (zeroed inside) and, optionally,
+ *                   tiles_per_gauss[C*N].
+ * gsr_isect_scan  : exclusive scan -> tile_offsets[n_tiles+1] (last = n_isects).
+ * gsr_isect_emit  : scatter (depth_bits<<32 | g) into the tile buckets.
+ *                   tile_cursor[n_tiles] is scratch (zeroed inside).
+ * gsr_tile_sort   : sort every bucket ascending (depth, then g) in place and
+ *                   write flatten_ids[n_isects] = g. big_list is scratch for
+ *                   the queue of buckets too long for the 16 KB LDS sorter.
+ * --------------------------------------------------------------------------*/
+int gsr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_w,
+                    int tile_h, int32_t *tiles_per_gauss /* or NULL */, int32_t *tile_counts,
+                    void *stream);
+int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets, void *stream);
+int gsr_isect_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                   int tile_w, int tile_h, const int32_t *tile_offsets, int32_t *tile_cursor,
+                   uint64_t *isect_keys, int64_t capacity, void *stream);
+int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets, uint64_t *isect_keys,
+                  int32_t *flatten_ids, int32_t *big_list /* scratch [n_tiles+1] */,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------
+ * A6 / A7: alpha compositing, one wave64 per 16x16 tile, 2x2 pixels per lane.
+ * opacities is [N] (opac_per_camera = 0) or [C,N] (1). backgrounds [C,CH] or
+ * NULL. last_ids [C,H,W] int32 is the flat index (into flatten_ids) of the
+ * last Gaussian blended into a pixel, -1 if none.
+ * --------------------------------------------------------------------------*/
+int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, const float *conics,
+                      const float *colors, int color_stride, const float *opacities,
+                      int opac_per_camera, const float *backgrounds, int width, int height,
+                      int tile_w, int tile_h, const int32_t *tile_offsets,
+                      const int32_t *flatten_ids, float *render_colors, float *render_alphas,
+                      int32_t *last_ids, void *stream);
+int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *conics,
+                      const float *colors, int color_stride, const float *opacities,
+                      int opac_per_camera, const float *backgrounds, int width, int height,
+                      int tile_w, int tile_h, const int32_t *tile_offsets,
+                      const int32_t *flatten_ids, const float *render_alphas,
+                      const int32_t *last_ids, const float *v_render_colors,
+                      const float *v_render_alphas, int absgrad,
+                      float *grad_rows /* [C*N,16], zeroed by caller, accumulated */, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Init path (monocular depth -> seed point cloud).
+ * --------------------------------------------------------------------------*/
+/* B2: normal-equation sums of d=(depth,1), g over M samples gathered from the
+ * depth map at integer (x,y) coords. sums_out[5] (fp64, device) =
+ * {sum d^2, sum d, M, sum d*g, sum g}. coords is [2,M] int64 (row 0 = x). */
+int gsr_lstsq_sums(int M, const float *depth_map, int depth_w, const int64_t *coords,
+                   const float *gt, double *sums_out, void *stream);
+/* Gather depth_map[y,x] at coords -> out[M]. */
+int gsr_gather_depth(int M, const float *depth_map, int depth_w, const int64_t *coords,
+                     float *out, void *stream);
+/* B3: score T hypotheses (scale,shift)[T,2] against M correspondences in one
+ * launch: squared residual r = (s*d+t-g)^2; out_ransac[T] = #(r >= thr)
+ * (int32), out_msac[T] = sum min(r,thr) (fp32), out_inliers[T] = #(r < thr). */
+int gsr_ransac_score(int T, int M, const float *hyp, const float *d, const float *g, float thr,
+                     int32_t *out_ransac, float *out_msac, int32_t *out_inliers, void *stream);
+/* Inlier-restricted normal-equation sums for T hypotheses: sums_out[T,5] fp64. */
+int gsr_ransac_lo_sums(int T, int M, const float *hyp, const float *d, const float *g, float thr,
+                       double *sums_out, void *stream);
+/* aligned = depth*scale + shift over H*W (scale/shift read from device hs[2]). */
+int gsr_affine_depth(int64_t n, const float *depth, const float *hs, float *out, void *stream);
+
+/* B5/B6: per-pixel subsampling factor map. mode 0: static factor k.
+ * mode 1: adaptive (lo/hi = IQR-clipped range read from device range[2]),
+ * factor = trunc(clamp(fmin + (fmax-fmin)*(1-clamp((d-lo)/(hi-lo),0,1)))),
+ * invalid pixels use multiplier 0.5. Writes keep[H*W] (uint8):
+ * y%f==0 && x%f==0 && valid. */
+int gsr_subsample_mask(int H, int W, int mode, int static_k, const float *depth,
+                       const uint8_t *valid, const float *range, int fmin, int fmax,
+                       uint8_t *keep, void *stream);
+/* B7: patch-density mask: patch_counts[gh*gw] (zeroed inside) histogram of
+ * SfM points, mask[H*W] = 0 where its patch holds > threshold points. */
+int gsr_sfm_patch_mask(int H, int W, int M, const int64_t *coords, int ph, int pw, int gh,
+                       int gw, int threshold, int32_t *patch_counts, uint8_t *mask,
+                       void *stream);
+/* B8: depth-gradient mask (|dx|+|dy| forward differences, min-max normalised). */
+int gsr_depth_grad(int H, int W, const float *depth, float *grad, void *stream);
+/* B9: fused mask -> stream compaction -> unprojection.
+ * keep = subsample[i] & valid[i] & (depth[i] >= 0) [& extra[i]].
+ * Pass 1 (gsr_unproject_count) writes block_counts; the caller scans them
+ * with gsr_isect_scan; pass 2 writes pts[n,3], rgb_out[n,3] in pixel order
+ * (identical to boolean-mask indexing) and final_mask[H*W].
+ * Kinv [3,3], c2w [4,4] device pointers. */
+int gsr_unproject_count(int H, int W, const float *depth, const uint8_t *valid,
+                        const uint8_t *subsample, const uint8_t *extra, int32_t *block_counts,
+                        int *n_blocks_out_host, void *stream);
+int gsr_unproject_emit(int H, int W, const float *depth, const uint8_t *valid,
+                       const uint8_t *subsample, const uint8_t *extra, const float *rgb,
+                       const float *Kinv, const float *c2w, const int32_t *block_offsets,
+                       float *pts, float *rgb_out, uint8_t *final_mask, void *stream);
+/* Number of compaction blocks gsr_unproject_count uses for an H x W image. */
+int gsr_unproject_num_blocks(int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H */
