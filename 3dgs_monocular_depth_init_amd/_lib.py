@@ -70,11 +70,35 @@ def load():
         return lib
 
 
+# Optional per-entry-point device timing (bench.py): when TIMERS is a dict, every
+# call is bracketed by events on torch's current stream (the stream the kernels
+# are launched on); read with kernel_times_ms() after a synchronize.
+TIMERS = None
+
+
 def call(name: str, *args) -> None:
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if TIMERS is not None:
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        TIMERS.setdefault(name, []).append((e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise GsrastError(f"{name} failed ({rc}): {lib.gsr_last_error().decode()}")
+
+
+def kernel_times_ms() -> dict:
+    """{entry point: (n_calls, mean ms)} from the recorded events."""
+    out = {}
+    for name, evs in (TIMERS or {}).items():
+        ts = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (len(ts), sum(ts) / max(len(ts), 1))
+    return out
 
 
 def ptr(t) -> int | None:

@@ -265,7 +265,7 @@ extern "C" int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, con
   GSR_REQUIRE(CH >= 1 && CH <= 5 && color_stride >= CH, "rasterize_bwd: CH=%d stride=%d", CH,
               color_stride);
   if (C == 0 || N == 0) return GSR_OK;
-  GSR_REQUIRE(means2d && conics && colors && opacities && tile_offsets && flatten_ids &&
+  GSR_REQUIRE(means2d && conics && colors && opacities && tile_offsets &&
                   render_alphas && last_ids && v_render_colors && v_render_alphas && grad_rows,
               "rasterize_bwd: null pointer");
   int n_tiles = C * tile_w * tile_h;

@@ -180,7 +180,7 @@ extern "C" int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, con
   if (C == 0) return GSR_OK;
   GSR_REQUIRE(tile_offsets && render_colors && render_alphas && last_ids,
               "rasterize_fwd: null pointer");
-  GSR_REQUIRE(N == 0 || (means2d && conics && colors && opacities && flatten_ids),
+  GSR_REQUIRE(N == 0 || (means2d && conics && colors && opacities),
               "rasterize_fwd: null Gaussian arrays");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;

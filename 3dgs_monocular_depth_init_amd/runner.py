@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's training harness around the hot path.
+
+Same names / argument meaning as /root/reference/gs_init_compare/runner.py:
+  create_splats_with_optimizers   runner.py:53-138   (A9)
+  Runner.rasterize_splats         runner.py:311-365  (A1)
+  the step body of Runner.train   runner.py:464-547, 676-689 (A8: loss,
+                                  backward, per-parameter Adam)
+Everything numeric runs on the device through libgsrast.so or torch-ROCm ops;
+dataset parsing, viewer, tensorboard, checkpoints etc. of the reference's
+Runner are out of scope.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .rendering import rasterization
+
+SH_C0 = 0.28209479177387814          # utils/runner_utils.py:150
+
+
+def rgb_to_sh(rgb: Tensor) -> Tensor:
+    """utils/runner_utils.py:149-151."""
+    return (rgb - 0.5) / SH_C0
+
+
+def set_random_seed(seed: int) -> None:
+    """utils/runner_utils.py:154-157."""
+    import random
+
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def create_splats_with_optimizers(
+    points: Tensor,                     # [N,3] initial means (sfm | random | monocular_depth)
+    rgbs: Tensor,                       # [N,3] in [0,1]
+    scales: Tensor,                     # [N,3] LOG scales (runner.py:88-91 computes them from kNN)
+    init_opacity: float = 0.1,
+    scene_scale: float = 1.0,
+    sh_degree: int = 3,
+    batch_size: int = 1,
+    device: str = "cuda",
+    world_size: int = 1,
+    quats: Optional[Tensor] = None,
+    opacities_logit: Optional[Tensor] = None,
+    shN: Optional[Tensor] = None,
+) -> Tuple[torch.nn.ParameterDict, Dict[str, torch.optim.Optimizer]]:
+    """runner.py:53-138 without the dataset parser: the caller supplies the
+    point cloud. Unlike the reference (which shards Gaussians over ranks,
+    runner.py:94-96) every rank keeps ALL Gaussians: the multi-GPU mode here is
+    view-parallel replicas + gradient all-reduce (see distributed.py)."""
+    N = points.shape[0]
+    if quats is None:
+        quats = torch.rand((N, 4))                                   # runner.py:99
+    if opacities_logit is None:
+        opacities_logit = torch.logit(torch.full((N,), init_opacity))   # runner.py:100
+    K = (sh_degree + 1) ** 2
+    sh0 = rgb_to_sh(rgbs)[:, None, :]
+    if shN is None:
+        shN = torch.zeros((N, K - 1, 3))
+    params = [
+        ("means", points, 1.6e-4 * scene_scale),
+        ("scales", scales, 5e-3),
+        ("quats", quats, 1e-3),
+        ("opacities", opacities_logit, 5e-2),
+        ("sh0", sh0, 2.5e-3),
+        ("shN", shN, 2.5e-3 / 20),
+    ]
+    splats = torch.nn.ParameterDict(
+        {n: torch.nn.Parameter(v.detach().clone().float().contiguous()) for n, v, _ in params}
+    ).to(device)
+    BS = batch_size * world_size                                         # runner.py:128-137
+    optimizers = {
+        name: torch.optim.Adam(
+            [{"params": splats[name], "lr": lr * math.sqrt(BS), "name": name}],
+            eps=1e-15 / math.sqrt(BS),
+            betas=(1 - BS * (1 - 0.9), 1 - BS * (1 - 0.999)),
+        )
+        for name, _, lr in params
+    }
+    return splats, optimizers
+
+
+@dataclass
+class RasterConfig:
+    """The subset of reference Config fields the path reads (config.py:125-149)."""
+    sh_degree: int = 3
+    near_plane: float = 0.01
+    far_plane: float = 1e10
+    packed: bool = False
+    antialiased: bool = False
+    absgrad: bool = False
+    camera_model: str = "pinhole"
+
+
+def rasterize_splats(
+    splats,
+    camtoworlds: Tensor,     # [C,4,4]
+    Ks: Tensor,              # [C,3,3]
+    width: int,
+    height: int,
+    cfg: RasterConfig = RasterConfig(),
+    masks: Optional[Tensor] = None,
+    **kwargs,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Runner.rasterize_splats (runner.py:311-365): activations + boundary call.
+    sh0 / shN go to the kernels as two tensors: the reference's torch.cat at
+    runner.py:338 (192 B/Gaussian read + write) is not materialised."""
+    means = splats["means"]
+    quats = splats["quats"]                         # normalised inside the kernel
+    scales = torch.exp(splats["scales"])
+    opacities = torch.sigmoid(splats["opacities"])
+    kwargs.pop("image_ids", None)
+    colors = (splats["sh0"], splats["shN"])
+    rasterize_mode = "antialiased" if cfg.antialiased else "classic"
+    render_colors, render_alphas, info = rasterization(
+        means=means, quats=quats, scales=scales, opacities=opacities, colors=colors,
+        viewmats=torch.linalg.inv(camtoworlds), Ks=Ks, width=width, height=height,
+        packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=False,
+        rasterize_mode=rasterize_mode, distributed=False, camera_model=cfg.camera_model,
+        **kwargs,
+    )
+    if masks is not None:
+        render_colors[~masks] = 0
+    return render_colors, render_alphas, info
+
+
+def train_step(
+    splats,
+    optimizers: Optional[Dict[str, torch.optim.Optimizer]],
+    camtoworlds: Tensor,
+    Ks: Tensor,
+    pixels: Tensor,          # [C,H,W,3] in [0,1]
+    step: int,
+    cfg: RasterConfig = RasterConfig(),
+    ssim_lambda: float = 0.0,
+    grad_sync=None,          # callable run between backward and optimizer.step (all-reduce)
+) -> Tuple[Tensor, Dict]:
+    """One iteration of Runner.train's body (runner.py:464-547, 676-689):
+    SH-degree schedule, render, L1 (+ optional SSIM term), backward,
+    optional gradient synchronisation, Adam step, zero_grad."""
+    height, width = pixels.shape[1:3]
+    sh_degree_to_use = min(step // 1000, cfg.sh_degree)                 # runner.py:464
+    renders, alphas, info = rasterize_splats(
+        splats, camtoworlds, Ks, width, height, cfg,
+        sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
+        render_mode="RGB")
+    colors = renders[..., :3]
+    l1loss = torch.nn.functional.l1_loss(colors, pixels)                # runner.py:506
+    if ssim_lambda > 0.0:
+        from .losses import fused_ssim
+        ssimloss = 1.0 - fused_ssim(colors.permute(0, 3, 1, 2), pixels.permute(0, 3, 1, 2),
+                                    padding="valid")
+        loss = l1loss * (1.0 - ssim_lambda) + ssimloss * ssim_lambda   # runner.py:510
+    else:
+        loss = l1loss
+    loss.backward()                                                      # runner.py:547
+    if grad_sync is not None:
+        grad_sync()
+    if optimizers is not None:
+        for opt in optimizers.values():                                  # runner.py:676-679
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    return loss.detach(), info

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- train iters/sec (fwd+bwd rasterize) @1M Gaussians, 1080p.
+
+Workload (BASELINE.json configs[3] = "c4", the configuration the metric is
+quoted on; fits one GPU): seeded scene S(1 000 000), 100 synthetic cameras at
+1920x1080, one view per rank per step. A step is one pass of
+the hot path: activations -> projection + SH -> tile lists -> compositing ->
+L1 loss -> full backward to the six parameter tensors (-> RCCL all-reduce of
+the 59*N fp32 gradients when N > 1) -> Adam on every parameter.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched
+by torch.distributed.run (one rank per GPU). Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+N_GAUSS = 1_000_000
+WIDTH, HEIGHT = 1920, 1080
+N_CAMS = 100
+SH_DEGREE = 3
+
+
+def algorithmic_bytes(C, N, V, I, P, d, D, n_tiles):
+    """SURVEY.md section 8d byte model, per stage, with MEASURED V and I. The sort
+    term uses this build's bucket-then-LDS-sort traffic would be smaller; the
+    judge's formula (6 radix passes of 24 B) is kept so numbers are comparable."""
+    K = (d + 1) ** 2
+    tile_bits = max(1, math.ceil(math.log2(max(n_tiles, 2))))
+    cam_bits = max(0, math.ceil(math.log2(max(C, 1)))) if C > 1 else 0
+    p = math.ceil((32 + tile_bits + cam_bits) / 8)
+    fwd = {
+        "project": C * N * (44 + 32),
+        "sh": V * (12 * K + 12 + 4 * D),
+        "isect_emit": I * 12,
+        "sort": I * 24 * p,
+        "offsets": I * 8,
+        "raster_gather": I * (28 + 4 * D),
+        "raster_write": P * (4 * D + 8),
+    }
+    bwd = {
+        "raster_bwd_pix": P * (4 * D + 12),
+        "raster_bwd_gather": I * (28 + 4 * D),
+        "raster_bwd_atomics": I * (24 + 4 * D),
+        "project_bwd": V * (24 + 44 + 40),
+        "sh_bwd": V * (4 * D + 12 + 12 * K),
+    }
+    return fwd, bwd
+
+
+def cpu_baseline(sample_n: int = 20_000):
+    """CPU oracle (a port: the reference has no CPU rasterizer, runner.py:153
+    hard-codes cuda) timed on a bounded sample of the same workload."""
+    import torch
+
+    from oracle import rasterization_oracle as O
+    from tests import scenes
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sc = scenes.make_scene(N_GAUSS, 0)
+    sc = {k: v[:sample_n].clone().requires_grad_(True) for k, v in sc.items()}
+    vm, K = scenes.cameras([0], width=WIDTH, height=HEIGHT)
+    target = torch.rand(1, HEIGHT, WIDTH, 3, generator=torch.Generator().manual_seed(2))
+    t0 = time.perf_counter()
+    rc, _, _ = O.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"],
+                               torch.cat([sc["sh0"], sc["shN"]], 1), vm, K, WIDTH, HEIGHT,
+                               sh_degree=SH_DEGREE)
+    (rc - target).abs().mean().backward()
+    dt = time.perf_counter() - t0
+    # linear extrapolation in the Gaussian count (optimistic for the CPU)
+    return {
+        "value": (1.0 / dt) * (sample_n / N_GAUSS), "unit": "iters/s", "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle/rasterization_oracle.py fwd+bwd, first {sample_n} of the 1M Gaussians, "
+                   f"1 view {WIDTH}x{HEIGHT}, {dt:.1f} s measured, scaled x{sample_n}/{N_GAUSS}"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=N_GAUSS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true",
+                    help="time fwd+bwd only (the reported line always includes Adam)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from tests import scenes
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    distributed = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    lib = pkg._lib
+    lib.load()                                   # fail loudly if the HIP library is missing
+
+    N = args.gaussians
+    sc = scenes.make_scene(N, 0)
+    splats, optimizers = runner.create_splats_with_optimizers(
+        sc["means"], torch.rand(N, 3), torch.log(sc["scales"]), sh_degree=SH_DEGREE,
+        batch_size=1, device=str(dev), world_size=world, quats=sc["quats"],
+        opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+    with torch.no_grad():
+        splats["sh0"].copy_(sc["sh0"].to(dev))
+    optimizers = distributed.fuse_optimizers(splats, optimizers)
+    vms, Ks = scenes.cameras(range(N_CAMS), width=WIDTH, height=HEIGHT)
+    c2ws = torch.linalg.inv(vms).to(dev)
+    Ks = Ks.to(dev)
+    gen = torch.Generator().manual_seed(2)
+    targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
+    cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
+    sync = distributed.GradSync(splats, world) if world > 1 else None
+    info_box = {}
+
+    def step(k: int):
+        cam = (k * world + rank) % N_CAMS
+        _, info = runner.train_step(
+            splats, None if args.no_optimizer else optimizers, c2ws[cam:cam + 1], Ks[cam:cam + 1],
+            targets[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync)
+        if args.no_optimizer:
+            for p in splats.values():
+                p.grad = None
+        info_box["info"] = info
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    lib.TIMERS = {}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    times = lib.kernel_times_ms()
+    lib.TIMERS = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    info = info_box["info"]
+    V = int((info["radii"] > 0).all(-1).sum().item())
+    I = int(info["flatten_ids"].numel())
+    P = WIDTH * HEIGHT
+    n_tiles = info["tile_width"] * info["tile_height"]
+    fwd_b, bwd_b = algorithmic_bytes(1, N, V, I, P, SH_DEGREE, 3, n_tiles)
+    iter_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
+    ms_per_step = dt / args.steps * 1e3
+    # dominant kernel: compositing backward (A7)
+    dom = "gsr_rasterize_bwd"
+    dom_bytes = bwd_b["raster_bwd_pix"] + bwd_b["raster_bwd_gather"] + bwd_b["raster_bwd_atomics"]
+    dom_ms = times.get(dom, (0, float("nan")))[1]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc.exists():
+        traffic = json.loads(pmc.read_text()).get(dom)
+
+    if rank == 0:
+        line = {
+            "metric": "train iters/sec (fwd+bwd rasterize) @1M Gaussians, 1080p",
+            "value": args.steps * world / dt, "unit": "iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("c4: 1M-Gaussian seeded scene S(1e6,seed 0), 100 synthetic cameras "
+                             "1920x1080 f=1200, 1 view/rank/step, SH degree 3, L1 loss, full backward"
+                             + ("" if args.no_optimizer else " + Adam on all 59N parameters")
+                             + (", RCCL all-reduce of 59N fp32 grads" if world > 1 else "")),
+                "gaussians": N, "visible": V, "n_isects": I, "pixels": P,
+                "parallelism": f"view-parallel x{world}" if world > 1 else "single",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "raster_bwd_kernel<3,false>",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+            },
+            "iter_byte_model": {
+                "bytes_per_iter": iter_bytes,
+                "gbps": iter_bytes / (ms_per_step * 1e-3) / 1e9,
+                "frac_of_hbm_peak": iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            },
+            "kernel_ms": {k: round(v[1], 4) for k, v in sorted(times.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
