@@ -8,10 +8,18 @@
 // as [64][16] rows; each row is then flushed with ONE 64-byte-aligned group
 // of float atomics into grad_rows[g][16] (16 adjacent lanes = one memory-side
 // atomic request), instead of 9-11 scattered dword atomics per Gaussian.
-#include "common.h"
-#include "gs_math.h"
+#include "raster_common.h"
 
 namespace gsr {
+
+// Sum over the 16 lanes of each DPP row; every lane of a row ends with the row sum.
+__device__ __forceinline__ float row_sum16(float v) {
+  v = dpp_add<0xb1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4e>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x124>(v);   // row_ror:4
+  v = dpp_add<0x128>(v);   // row_ror:8
+  return v;
+}
 
 template <int CH, bool ABSGRAD>
 __global__ void __launch_bounds__(64)
@@ -24,13 +32,11 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
                   const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows) {
-  constexpr int NC = (CH > 2) ? (CH - 2) : 1;
   __shared__ float4 sA[2][64];
   __shared__ float4 sB[2][64];
-  __shared__ float sC[2][64][NC];
+  __shared__ float4 sC[2][64];
   __shared__ int sId[2][64];
-  __shared__ float sG[64][GSR_GRAD_ROW];  // reduced gradients of the batch
-  __shared__ int sTouched[64];
+  __shared__ __attribute__((aligned(16))) float sG[64][GSR_GRAD_ROW];  // batch gradient rows
 
   const int tile = xcd_remap(blockIdx.x, n_tiles);
   if (tile >= n_tiles) return;
@@ -39,182 +45,178 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   const int tin = tile - cam * tiles_per_cam;
   const int ty = tin / tile_w, tx = tin - ty * tile_w;
   const int lane = threadIdx.x;
-  const int qx = lane & 7, qy = lane >> 3;
-  const int x0 = tx * GSR_TILE + 2 * qx, y0 = ty * GSR_TILE + 2 * qy;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
 
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e <= s) return;
 
-  float px[4], py[4], T[4], Tfin[4], buf_c[4][CH], vout[4][CH], valpha[4];
-  int last[4];
+  // Kq = T_final * (v_alpha_out - <background, v_out>): the per-pixel constant of v_alpha
+  float px[4], py[2], T[4], Kq[4], buf_c[4][CH], vout[4][CH];
+  int last[4], qmax[4];
+  py[0] = (float)(ty0 + ly) + 0.5f;
+  py[1] = py[0] + 8.0f;
   int max_last = -1;
-  float bgdot[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int x = x0 + (p & 1), y = y0 + (p >> 1);
-    px[p] = (float)x + 0.5f;
-    py[p] = (float)y + 0.5f;
-    const bool inside = (x < width) && (y < height);
-    last[p] = -1;
-    Tfin[p] = 1.f;
-    valpha[p] = 0.f;
-    bgdot[p] = 0.f;
+  for (int q = 0; q < 4; ++q) {
+    const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
+    px[q] = (float)x + 0.5f;
+    last[q] = -1;
+    T[q] = 1.f;
+    Kq[q] = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      vout[p][k] = 0.f;
-      buf_c[p][k] = 0.f;
+      vout[q][k] = 0.f;
+      buf_c[q][k] = 0.f;
     }
-    if (inside) {
+    if (x < width && y < height) {
       const int64_t pix = ((int64_t)cam * height + y) * width + x;
-      last[p] = last_ids[pix];
-      Tfin[p] = 1.0f - render_alphas[pix];
-      valpha[p] = v_render_alphas[pix];
+      last[q] = last_ids[pix];
+      T[q] = 1.0f - render_alphas[pix];
+      float kk = v_render_alphas[pix];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) vout[p][k] = v_render_colors[pix * CH + k];
+      for (int k = 0; k < CH; ++k) vout[q][k] = v_render_colors[pix * CH + k];
       if (backgrounds) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k) bgdot[p] += backgrounds[cam * CH + k] * vout[p][k];
+        for (int k = 0; k < CH; ++k) kk -= backgrounds[cam * CH + k] * vout[q][k];
       }
+      Kq[q] = T[q] * kk;
     }
-    T[p] = Tfin[p];
-    max_last = max(max_last, last[p]);
+    qmax[q] = __builtin_amdgcn_readfirstlane(wave_max_i32(last[q]));
+    max_last = max(max_last, qmax[q]);
   }
-  max_last = wave_max_i32(max_last);
-  if (max_last < s) return;  // nothing was blended into this tile
+  if (max_last < s) return;  // nothing was blended into this tile (wave-uniform)
   const int start = min(max_last, e - 1);
 
-  // lane l of a batch holds Gaussian (batch_end - l): j = 0 is the LAST one.
-  float4 rA, rB;
-  float rC[NC];
+  // lane l of a batch stages Gaussian (batch_end - l): j = 0 is the LAST one.
+  TileRec<CH> rec;
   int rId = 0;
-  auto gather = [&](int idx) {
-    const int g = flatten_ids[idx];
-    rId = g;
-    const float2 m = *reinterpret_cast<const float2 *>(means2d + (int64_t)g * 2);
-    const float *cn = conics + (int64_t)g * 3;
-    const float *cl = colors + (int64_t)g * color_stride;
-    const float op = opacities[opac_per_camera ? g : (g % N)];
-    rA = make_float4(m.x, m.y, cn[0], cn[1]);
-    rB = make_float4(cn[2], op, cl[0], (CH > 1) ? cl[1] : 0.f);
-#pragma unroll
-    for (int k = 2; k < CH; ++k) rC[k - 2] = cl[k];
-  };
-  if (start - lane >= s) gather(start - lane);
+  if (start - lane >= s) {
+    rId = flatten_ids[start - lane];
+    stage_gauss<CH>(rId, N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
+                    (float)tx0, (float)ty0, rec);
+  }
 
   int buf = 0;
   for (int batch_end = start; batch_end >= s; batch_end -= 64) {
     const int n = min(64, batch_end - s + 1);
     if (lane < n) {
-      sA[buf][lane] = rA;
-      sB[buf][lane] = rB;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) sC[buf][lane][k] = rC[k];
+      sA[buf][lane] = rec.a;
+      sB[buf][lane] = rec.b;
+      sC[buf][lane] = rec.c;
       sId[buf][lane] = rId;
     }
-    sTouched[lane] = 0;
+    sG[lane][15] = 0.f;   // "row touched" flag of Gaussian `lane` of this batch
     __syncthreads();
     const int nb = batch_end - 64;
-    if (nb - lane >= s) gather(nb - lane);
+    if (nb - lane >= s) {
+      rId = flatten_ids[nb - lane];
+      stage_gauss<CH>(rId, N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
+                      (float)tx0, (float)ty0, rec);
+    }
 
     for (int j = 0; j < n; ++j) {
+      const float4 Ac = sA[buf][j], Bc = sB[buf][j], Cc = sC[buf][j];
       const int idx = batch_end - j;
-      const float4 A = sA[buf][j];
-      const float4 B = sB[buf][j];
+      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(Cc.w));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (idx > qmax[q]) qm &= ~(1u << q);   // scalar: no pixel of q blended this far down
+      if (qm == 0) continue;
       float col[CH];
-      col[0] = B.z;
-      if (CH > 1) col[1] = B.w;
-#pragma unroll
-      for (int k = 2; k < CH; ++k) col[k] = sC[buf][j][k - 2];
-      const float opac = B.y;
-
-      float dx[4], dy[4], vis[4], alpha[4];
-      bool valid[4];
-      bool any_valid = false;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        dx[p] = A.x - px[p];
-        dy[p] = A.y - py[p];
-        const float sigma = 0.5f * (A.z * dx[p] * dx[p] + B.x * dy[p] * dy[p]) + A.w * dx[p] * dy[p];
-        vis[p] = __expf(-sigma);
-        alpha[p] = fminf(gs::ALPHA_MAX, opac * vis[p]);
-        valid[p] = (idx <= last[p]) && (sigma >= 0.f) && (alpha[p] >= gs::ALPHA_THRESHOLD);
-        any_valid |= valid[p];
-      }
-      if (!__any(any_valid)) continue;  // wave-uniform skip
+      col[0] = Bc.z;
+      if (CH > 1) col[1] = Bc.w;
+      if (CH > 2) col[2] = Cc.x;
+      if (CH > 3) col[3] = Cc.y;
+      if (CH > 4) col[4] = Cc.z;
+      const float opac = Bc.y;
+      // conic in natural units for the gradient formulas: a = 2*ha/log2e etc.
+      const float ca = Ac.z * (2.0f / LOG2E), cb = Ac.w * (1.0f / LOG2E), cc = Bc.x * (2.0f / LOG2E);
 
       float g_xy[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_col[CH];
       float g_abs[2] = {0.f, 0.f};
+      bool any_valid = false;
 #pragma unroll
       for (int k = 0; k < CH; ++k) g_col[k] = 0.f;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        if (valid[p]) {
-          const float ra = 1.0f / (1.0f - alpha[p]);
-          T[p] *= ra;
-          const float fac = alpha[p] * T[p];
-          float v_alpha = 0.f;
+      for (int q = 0; q < 4; ++q) {
+        if (qm & (1u << q)) {   // scalar branch
+          const float dx = Ac.x - px[q], dy = Ac.y - py[q >> 1];
+          const float sg = sigma_l2(Ac.z, Ac.w, Bc.x, dx, dy);
+          const float vis = __builtin_amdgcn_exp2f(-sg);
+          const float alpha = fminf(gs::ALPHA_MAX, opac * vis);
+          const bool valid = (idx <= last[q]) && (sg >= 0.f) && (alpha >= gs::ALPHA_THRESHOLD);
+          any_valid |= valid;
+          const float a = valid ? alpha : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+          T[q] *= ra;
+          const float fac = a * T[q];
+          float v_alpha = Kq[q] * ra;
 #pragma unroll
           for (int k = 0; k < CH; ++k) {
-            g_col[k] += fac * vout[p][k];
-            v_alpha += (col[k] * T[p] - buf_c[p][k] * ra) * vout[p][k];
+            g_col[k] = fmaf(fac, vout[q][k], g_col[k]);
+            v_alpha = fmaf(col[k] * T[q] - buf_c[q][k] * ra, vout[q][k], v_alpha);
+            buf_c[q][k] = fmaf(col[k], fac, buf_c[q][k]);
           }
-          v_alpha += Tfin[p] * ra * valpha[p];
-          if (backgrounds) v_alpha -= Tfin[p] * ra * bgdot[p];
-          if (opac * vis[p] <= gs::ALPHA_MAX) {
-            const float v_sigma = -opac * vis[p] * v_alpha;
-            g_con[0] += 0.5f * v_sigma * dx[p] * dx[p];
-            g_con[1] += v_sigma * dx[p] * dy[p];
-            g_con[2] += 0.5f * v_sigma * dy[p] * dy[p];
-            const float vx = v_sigma * (A.z * dx[p] + A.w * dy[p]);
-            const float vy = v_sigma * (A.w * dx[p] + B.x * dy[p]);
-            g_xy[0] += vx;
-            g_xy[1] += vy;
-            if (ABSGRAD) {
-              g_abs[0] += fabsf(vx);
-              g_abs[1] += fabsf(vy);
-            }
-            g_op += vis[p] * v_alpha;
+          const float ov = opac * vis;
+          const float va = (valid && ov <= gs::ALPHA_MAX) ? v_alpha : 0.f;
+          const float v_sigma = -ov * va;
+          const float tdx = v_sigma * dx, tdy = v_sigma * dy;
+          g_con[0] = fmaf(0.5f * tdx, dx, g_con[0]);
+          g_con[1] = fmaf(tdx, dy, g_con[1]);
+          g_con[2] = fmaf(0.5f * tdy, dy, g_con[2]);
+          const float vx = fmaf(ca, tdx, cb * tdy);
+          const float vy = fmaf(cb, tdx, cc * tdy);
+          g_xy[0] += vx;
+          g_xy[1] += vy;
+          if (ABSGRAD) {
+            g_abs[0] += fabsf(vx);
+            g_abs[1] += fabsf(vy);
           }
-#pragma unroll
-          for (int k = 0; k < CH; ++k) buf_c[p][k] += col[k] * fac;
+          g_op = fmaf(vis, va, g_op);
         }
       }
-      // wave reduction on DPP; totals are wave-uniform after readlane
-      const float r_x = wave_sum(g_xy[0]), r_y = wave_sum(g_xy[1]);
-      const float r_a = wave_sum(g_con[0]), r_b = wave_sum(g_con[1]), r_c = wave_sum(g_con[2]);
-      const float r_o = wave_sum(g_op);
+      if (!__any(any_valid)) continue;  // wave-uniform skip
+      // row reduction on DPP, then 4 lanes (one per row) add into the LDS row
+      const float r_x = row_sum16(g_xy[0]), r_y = row_sum16(g_xy[1]);
+      const float r_a = row_sum16(g_con[0]), r_b = row_sum16(g_con[1]), r_c = row_sum16(g_con[2]);
+      const float r_o = row_sum16(g_op);
       float r_col[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) r_col[k] = wave_sum(g_col[k]);
+      for (int k = 0; k < CH; ++k) r_col[k] = row_sum16(g_col[k]);
       float r_ax = 0.f, r_ay = 0.f;
       if (ABSGRAD) {
-        r_ax = wave_sum(g_abs[0]);
-        r_ay = wave_sum(g_abs[1]);
+        r_ax = row_sum16(g_abs[0]);
+        r_ay = row_sum16(g_abs[1]);
       }
-      // lane f writes field f of row j
-      float val = 0.f;
-      val = (lane == GSR_GR_MEAN2D) ? r_x : val;
-      val = (lane == GSR_GR_MEAN2D + 1) ? r_y : val;
-      val = (lane == GSR_GR_CONIC) ? r_a : val;
-      val = (lane == GSR_GR_CONIC + 1) ? r_b : val;
-      val = (lane == GSR_GR_CONIC + 2) ? r_c : val;
-      val = (lane == GSR_GR_OPAC) ? r_o : val;
+      // lane (16*row + f) picks field f of its row's sums, the four rows are
+      // folded with two cross-row shuffles, lanes 0..15 store the 64-byte row.
+      const int f16 = lane & 15;
+      float val = (f16 == 15) ? 1.0f : 0.f;          // field 15 = "row touched" flag
+      val = (f16 == GSR_GR_MEAN2D) ? r_x : val;
+      val = (f16 == GSR_GR_MEAN2D + 1) ? r_y : val;
+      val = (f16 == GSR_GR_CONIC) ? r_a : val;
+      val = (f16 == GSR_GR_CONIC + 1) ? r_b : val;
+      val = (f16 == GSR_GR_CONIC + 2) ? r_c : val;
+      val = (f16 == GSR_GR_OPAC) ? r_o : val;
 #pragma unroll
-      for (int k = 0; k < CH; ++k) val = (lane == GSR_GR_COLOR + k) ? r_col[k] : val;
+      for (int k = 0; k < CH; ++k) val = (f16 == GSR_GR_COLOR + k) ? r_col[k] : val;
       if (ABSGRAD) {
-        val = (lane == GSR_GR_ABS) ? r_ax : val;
-        val = (lane == GSR_GR_ABS + 1) ? r_ay : val;
+        val = (f16 == GSR_GR_ABS) ? r_ax : val;
+        val = (f16 == GSR_GR_ABS + 1) ? r_ay : val;
       }
+      val += __shfl_xor(val, 16, 64);
+      val += __shfl_xor(val, 32, 64);
       if (lane < GSR_GRAD_ROW) sG[j][lane] = val;
-      if (lane == 0) sTouched[j] = 1;
     }
     __syncthreads();
     // flush: 4 Gaussians per wave instruction, 16 lanes = one 64-byte row
     const int f = lane & 15;
-    const bool field_used = (f < GSR_GR_COLOR + CH) || (ABSGRAD && (f == GSR_GR_ABS || f == GSR_GR_ABS + 1));
+    const bool field_used =
+        (f < GSR_GR_COLOR + CH) || (ABSGRAD && (f == GSR_GR_ABS || f == GSR_GR_ABS + 1));
     for (int j0 = 0; j0 < n; j0 += 4) {
       const int j = j0 + (lane >> 4);
-      if (j < n && field_used && sTouched[j]) {
+      if (j < n && field_used && sG[j][15] != 0.f) {
         const int g = sId[buf][j];
         atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, sG[j][f]);
       }

@@ -1,0 +1,79 @@
+// raster_common.h -- pieces shared by the compositing forward and backward.
+//
+// Wave/tile shape (both kernels): ONE wave64 per 16x16 tile. The tile is cut
+// into four 8x8 quadrants; lane l owns pixel (l & 7, l >> 3) of EVERY quadrant
+// (4 pixels per lane). For each Gaussian of the tile list the staging lane
+// pre-computes a 4-bit quadrant mask by an exact ellipse-vs-rectangle test
+// (min of sigma over the quadrant's pixel centres <= ln(255*opacity), i.e. at
+// least one pixel could reach alpha >= 1/255). The mask is wave-uniform, so
+// the per-quadrant body is skipped with SCALAR branches: with ~5 px radii a
+// Gaussian touches ~2 of the 4 quadrants, which halves the VALU work without
+// changing any result (a skipped quadrant has alpha < 1/255 everywhere).
+#pragma once
+#include "common.h"
+#include "gs_math.h"
+
+namespace gsr {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float PIX_DONE = 1.0e18f;   // pixel x of a finished / outside pixel: sigma -> huge, alpha -> 0
+
+template <int CH>
+struct TileRec {      // LDS image of one staged Gaussian
+  float4 a;           // mx, my, ha = 0.5*a*log2e, bb = b*log2e
+  float4 b;           // hc = 0.5*c*log2e, opacity, col0, col1
+  float4 c;           // col2, col3, col4, quadrant mask (int bits)
+};
+
+// sigma' = log2(e) * sigma, evaluated identically in forward and backward.
+__device__ __forceinline__ float sigma_l2(float ha, float bb, float hc, float dx, float dy) {
+  float s = (ha * dx) * dx;
+  s = fmaf(hc * dy, dy, s);
+  return fmaf(bb * dx, dy, s);
+}
+
+// min over the rectangle of pixel centres [x0,x1]x[y0,y1] of
+// sigma(d) = 0.5*(a dx^2 + c dy^2) + b dx dy, d = mean - pixel.
+__device__ __forceinline__ float min_sigma_rect(float a, float b, float c, float mx, float my,
+                                                float x0, float x1, float y0, float y1) {
+  const float dxlo = mx - x1, dxhi = mx - x0, dylo = my - y1, dyhi = my - y0;
+  if (dxlo <= 0.f && dxhi >= 0.f && dylo <= 0.f && dyhi >= 0.f) return 0.f;
+  auto sig = [&](float dx, float dy) { return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy; };
+  const float ic = 1.0f / c, ia = 1.0f / a;
+  float m = sig(dxlo, fminf(fmaxf(-b * dxlo * ic, dylo), dyhi));
+  m = fminf(m, sig(dxhi, fminf(fmaxf(-b * dxhi * ic, dylo), dyhi)));
+  m = fminf(m, sig(fminf(fmaxf(-b * dylo * ia, dxlo), dxhi), dylo));
+  m = fminf(m, sig(fminf(fmaxf(-b * dyhi * ia, dxlo), dxhi), dyhi));
+  return m;
+}
+
+// Gather Gaussian g and build its LDS record for the tile at pixel origin (tx0, ty0).
+template <int CH>
+__device__ __forceinline__ void stage_gauss(int g, int N, const float *__restrict__ means2d,
+                                            const float *__restrict__ conics,
+                                            const float *__restrict__ colors, int color_stride,
+                                            const float *__restrict__ opacities,
+                                            int opac_per_camera, float tx0, float ty0,
+                                            TileRec<CH> &r) {
+  const float2 m = *reinterpret_cast<const float2 *>(means2d + (int64_t)g * 2);
+  const float *cn = conics + (int64_t)g * 3;
+  const float *cl = colors + (int64_t)g * color_stride;
+  const float op = opacities[opac_per_camera ? g : (g % N)];
+  const float a = cn[0], b = cn[1], c = cn[2];
+  // alpha >= 1/255  <=>  sigma <= ln(255*op); small margin keeps the test conservative
+  const float tau = logf(op * 255.0f);
+  const float tau_m = tau + 1e-4f * (1.0f + fabsf(tau));
+  int qmask = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = tx0 + 8.f * (float)(q & 1) + 0.5f, y0 = ty0 + 8.f * (float)(q >> 1) + 0.5f;
+    const float ms = min_sigma_rect(a, b, c, m.x, m.y, x0, x0 + 7.f, y0, y0 + 7.f);
+    qmask |= (ms <= tau_m) ? (1 << q) : 0;
+  }
+  r.a = make_float4(m.x, m.y, 0.5f * a * LOG2E, b * LOG2E);
+  r.b = make_float4(0.5f * c * LOG2E, op, cl[0], (CH > 1) ? cl[1] : 0.f);
+  r.c = make_float4((CH > 2) ? cl[2] : 0.f, (CH > 3) ? cl[3] : 0.f, (CH > 4) ? cl[4] : 0.f,
+                    __int_as_float(qmask));
+}
+
+}  // namespace gsr

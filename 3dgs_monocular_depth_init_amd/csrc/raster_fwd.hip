@@ -7,35 +7,9 @@
 // no cross-wave barriers, wave-uniform early exit). The tile's depth-sorted
 // list is streamed through LDS in batches of 64 Gaussians, double-buffered:
 // the gather of batch k+1 is in flight while batch k is composited.
-#include "common.h"
-#include "gs_math.h"
+#include "raster_common.h"
 
 namespace gsr {
-
-template <int CH>
-struct GaussRec {          // what one lane gathers for one Gaussian
-  float4 a;                // mx, my, conic a, conic b
-  float4 b;                // conic c, opacity, col0, col1
-  float c[(CH > 2) ? (CH - 2) : 1];  // remaining colour channels
-};
-
-template <int CH>
-__device__ __forceinline__ void gather_gauss(int g, int N, const float *__restrict__ means2d,
-                                             const float *__restrict__ conics,
-                                             const float *__restrict__ colors, int color_stride,
-                                             const float *__restrict__ opacities,
-                                             int opac_per_camera, GaussRec<CH> &r) {
-  float2 m = *reinterpret_cast<const float2 *>(means2d + (int64_t)g * 2);
-  const float *cn = conics + (int64_t)g * 3;
-  const float *cl = colors + (int64_t)g * color_stride;
-  float op = opacities[opac_per_camera ? g : (g % N)];
-  r.a = make_float4(m.x, m.y, cn[0], cn[1]);
-  float c0 = cl[0];
-  float c1 = (CH > 1) ? cl[1] : 0.f;
-  r.b = make_float4(cn[2], op, c0, c1);
-#pragma unroll
-  for (int k = 2; k < CH; ++k) r.c[k - 2] = cl[k];
-}
 
 template <int CH>
 __global__ void __launch_bounds__(64)
@@ -46,10 +20,9 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ flatten_ids, float *__restrict__ render_colors,
                   float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
-  constexpr int NC = (CH > 2) ? (CH - 2) : 1;
   __shared__ float4 sA[2][64];
   __shared__ float4 sB[2][64];
-  __shared__ float sC[2][64][NC];
+  __shared__ float4 sC[2][64];
 
   const int tile = xcd_remap(blockIdx.x, n_tiles);
   if (tile >= n_tiles) return;
@@ -58,73 +31,89 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   const int tin = tile - cam * tiles_per_cam;
   const int ty = tin / tile_w, tx = tin - ty * tile_w;
   const int lane = threadIdx.x;
-  const int qx = lane & 7, qy = lane >> 3;
-  const int x0 = tx * GSR_TILE + 2 * qx, y0 = ty * GSR_TILE + 2 * qy;
+  const int lx = lane & 7, ly = lane >> 3;
+  const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
 
-  float px[4], py[4], T[4], acc[4][CH];
+  // pixel q of this lane: (tx0 + 8*(q&1) + lx, ty0 + 8*(q>>1) + ly)
+  float px[4], py[2], T[4], acc[4][CH];
   int last[4];
-  unsigned done = 0;  // bit p: pixel p finished (or outside the image)
+  unsigned outside = 0;
+  py[0] = (float)(ty0 + ly) + 0.5f;
+  py[1] = py[0] + 8.0f;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int x = x0 + (p & 1), y = y0 + (p >> 1);
-    px[p] = (float)x + 0.5f;
-    py[p] = (float)y + 0.5f;
-    T[p] = 1.0f;
-    last[p] = -1;
-    if (x >= width || y >= height) done |= 1u << p;
+  for (int q = 0; q < 4; ++q) {
+    const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
+    px[q] = (float)x + 0.5f;
+    T[q] = 1.0f;
+    last[q] = -1;
+    if (x >= width || y >= height) {
+      outside |= 1u << q;
+      px[q] = PIX_DONE;
+    }
 #pragma unroll
-    for (int k = 0; k < CH; ++k) acc[p][k] = 0.f;
+    for (int k = 0; k < CH; ++k) acc[q][k] = 0.f;
   }
-  const unsigned outside = done;
 
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
-  GaussRec<CH> rec;
+  TileRec<CH> rec;
   if (s + lane < e)
-    gather_gauss<CH>(flatten_ids[s + lane], N, means2d, conics, colors, color_stride, opacities,
-                     opac_per_camera, rec);
+    stage_gauss<CH>(flatten_ids[s + lane], N, means2d, conics, colors, color_stride, opacities,
+                    opac_per_camera, (float)tx0, (float)ty0, rec);
   int buf = 0;
+  unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
   for (int base = s; base < e; base += 64) {
-    if (__all(done == 0xfu)) break;  // wave-uniform: every pixel of the tile is saturated
+    // drop quadrants whose 64 pixels are all finished (or outside the image)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!__any(px[q] != PIX_DONE)) live &= ~(1u << q);
+    if (live == 0) break;
     const int n = min(64, e - base);
     if (lane < n) {
       sA[buf][lane] = rec.a;
       sB[buf][lane] = rec.b;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) sC[buf][lane][k] = rec.c[k];
+      sC[buf][lane] = rec.c;
     }
     __syncthreads();
-    // prefetch the next batch while this one is composited
     const int nb = base + 64;
     if (nb + lane < e)
-      gather_gauss<CH>(flatten_ids[nb + lane], N, means2d, conics, colors, color_stride,
-                       opacities, opac_per_camera, rec);
-    {
-      for (int j = 0; j < n; ++j) {
-        const float4 A = sA[buf][j];
-        const float4 B = sB[buf][j];
-        float col[CH];
-        col[0] = B.z;
-        if (CH > 1) col[1] = B.w;
+      stage_gauss<CH>(flatten_ids[nb + lane], N, means2d, conics, colors, color_stride,
+                      opacities, opac_per_camera, (float)tx0, (float)ty0, rec);
+    float4 A = sA[buf][0], B = sB[buf][0], C4 = sC[buf][0];
+    for (int j = 0; j < n; ++j) {
+      // software prefetch of the next record (LDS latency under this Gaussian's math)
+      const int jn = min(j + 1, n - 1);
+      const float4 An = sA[buf][jn], Bn = sB[buf][jn], Cn = sC[buf][jn];
+      const float4 Ac = A, Bc = B, Cc = C4;
+      A = An;
+      B = Bn;
+      C4 = Cn;
+      const unsigned qm =
+          (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(Cc.w)) & live;
+      if (qm == 0) continue;
+      float col[CH];
+      col[0] = Bc.z;
+      if (CH > 1) col[1] = Bc.w;
+      if (CH > 2) col[2] = Cc.x;
+      if (CH > 3) col[3] = Cc.y;
+      if (CH > 4) col[4] = Cc.z;
+      const int idx = base + j;
 #pragma unroll
-        for (int k = 2; k < CH; ++k) col[k] = sC[buf][j][k - 2];
+      for (int q = 0; q < 4; ++q) {
+        if (qm & (1u << q)) {   // scalar branch
+          const float dx = Ac.x - px[q], dy = Ac.y - py[q >> 1];
+          const float sg = sigma_l2(Ac.z, Ac.w, Bc.x, dx, dy);
+          const float alpha = fminf(gs::ALPHA_MAX, Bc.y * __builtin_amdgcn_exp2f(-sg));
+          const bool ok = (sg >= 0.f) && (alpha >= gs::ALPHA_THRESHOLD);
+          float a = ok ? alpha : 0.f;
+          const float nT = fmaf(-a, T[q], T[q]);
+          const bool stop = nT <= gs::T_THRESHOLD;   // only possible when ok (T > threshold)
+          a = stop ? 0.f : a;
+          px[q] = stop ? PIX_DONE : px[q];
+          const float w = a * T[q];
+          T[q] -= w;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float dx = A.x - px[p], dy = A.y - py[p];
-          const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-          const float alpha = fminf(gs::ALPHA_MAX, B.y * __expf(-sigma));
-          const bool ok = (sigma >= 0.f) && (alpha >= gs::ALPHA_THRESHOLD) && !((done >> p) & 1u);
-          if (ok) {
-            const float nT = T[p] * (1.0f - alpha);
-            if (nT <= gs::T_THRESHOLD) {
-              done |= 1u << p;
-            } else {
-              const float w = alpha * T[p];
-#pragma unroll
-              for (int k = 0; k < CH; ++k) acc[p][k] += col[k] * w;
-              T[p] = nT;
-              last[p] = base + j;
-            }
-          }
+          for (int k = 0; k < CH; ++k) acc[q][k] = fmaf(col[k], w, acc[q][k]);
+          last[q] = (ok && !stop) ? idx : last[q];
         }
       }
     }
@@ -132,19 +121,19 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   }
 
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    if ((outside >> p) & 1u) continue;
-    const int x = x0 + (p & 1), y = y0 + (p >> 1);
+  for (int q = 0; q < 4; ++q) {
+    if ((outside >> q) & 1u) continue;
+    const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
     const int64_t pix = ((int64_t)cam * height + y) * width + x;
     float *out = render_colors + pix * CH;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      float v = acc[p][k];
-      if (backgrounds) v += T[p] * backgrounds[cam * CH + k];
+      float v = acc[q][k];
+      if (backgrounds) v += T[q] * backgrounds[cam * CH + k];
       out[k] = v;
     }
-    render_alphas[pix] = 1.0f - T[p];
-    last_ids[pix] = last[p];
+    render_alphas[pix] = 1.0f - T[q];
+    last_ids[pix] = last[q];
   }
 }
 
