@@ -26,14 +26,15 @@ SIGNATURES = {
     "gsr_project_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p, _p,
                         _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
     "gsr_isect_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p],
-    "gsr_isect_scan": [_i, _p, _p, _p],
+    "gsr_isect_scan": [_i, _p, _p, _p, _p],
     "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
-    "gsr_tile_sort": [_i, _p, _p, _p, _p, _p],
+    "gsr_tile_sort": [_i, _p, _p, _p, _p, _p, _p],
     "gsr_rasterize_fwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
-                          _p, _p],
+                          _p, _p, _p],
     "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
-                          _p, _p, _i, _p, _p],
+                          _p, _p, _p, _i, _p, _p],
 }
+SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]
 OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)
 
 

@@ -67,10 +67,22 @@ isect_emit_kernel(int C, int N, const float *__restrict__ means2d,
 
 // Exclusive scan of n int32 counts by ONE workgroup of 1024 threads, 8 items
 // per thread per sweep (n is the tile count: 8 160 per 1080p camera).
+//
+// It also emits tile_order: the tile ids bucketed by list length, longest
+// first (64 length classes of 32 entries). The compositing kernels take work
+// in this order, so the hardware dispatcher hands the long tiles out first
+// and the short ones fill the tail (longest-processing-time-first balance).
+constexpr int ORDER_BUCKETS = 64;
+__device__ __forceinline__ int order_bucket(int len) {
+  return ORDER_BUCKETS - 1 - min(ORDER_BUCKETS - 1, (len + 31) >> 5);   // 0 = longest
+}
+
 __global__ void __launch_bounds__(1024)
-scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
+scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
+            int32_t *__restrict__ tile_order) {
   __shared__ int32_t wave_tot[16];
   __shared__ int32_t carry_s;
+  __shared__ int32_t hist[ORDER_BUCKETS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
@@ -106,6 +118,24 @@ scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
     __syncthreads();
   }
   if (tid == 0) out[n] = carry_s;
+  if (!tile_order) return;
+  if (tid < ORDER_BUCKETS) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) atomicAdd(&hist[order_bucket(in[t])], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < ORDER_BUCKETS; ++b) {
+      int c = hist[b];
+      hist[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) {
+    int pos = atomicAdd(&hist[order_bucket(in[t])], 1);
+    tile_order[pos] = t;
+  }
 }
 
 // ---- per-tile bitonic sort (all-ascending network, virtual +inf padding) ----
@@ -151,11 +181,12 @@ constexpr int SORT_LARGE_CAP = 8192;   // 64 KB LDS, 1024 threads
 // queued for the large kernel.
 __global__ void __launch_bounds__(256)
 tile_sort_small_kernel(int n_tiles, const int32_t *__restrict__ tile_offsets,
-                       uint64_t *__restrict__ keys, int32_t *__restrict__ flatten_ids,
+                       const int32_t *__restrict__ tile_order, uint64_t *__restrict__ keys,
+                       int32_t *__restrict__ flatten_ids,
                        int32_t *__restrict__ big_list /* [0]=count, then tile ids */) {
   __shared__ uint64_t sk[SORT_SMALL_CAP];
-  int tile = xcd_remap(blockIdx.x, n_tiles);
-  if (tile >= n_tiles) return;
+  if ((int)blockIdx.x >= n_tiles) return;
+  int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   int s = tile_offsets[tile], e = tile_offsets[tile + 1];
   int L = e - s;
   if (L <= 0) return;
@@ -229,10 +260,10 @@ extern "C" int gsr_isect_count(int C, int N, const float *means2d, const int32_t
 }
 
 extern "C" int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets,
-                              void *stream) {
+                              int32_t *tile_order, void *stream) {
   GSR_REQUIRE(n_tiles >= 0 && tile_counts && tile_offsets, "isect_scan: bad arguments");
   hipLaunchKernelGGL(gsr::scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
-                     tile_counts, tile_offsets);
+                     tile_counts, tile_offsets, tile_order);
   GSR_CHECK_LAUNCH("isect_scan");
   return GSR_OK;
 }
@@ -257,14 +288,16 @@ extern "C" int gsr_isect_emit(int C, int N, const float *means2d, const int32_t 
   return GSR_OK;
 }
 
-extern "C" int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets, uint64_t *isect_keys,
+extern "C" int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
+                             const int32_t *tile_order, uint64_t *isect_keys,
                              int32_t *flatten_ids, int32_t *big_list, void *stream) {
   GSR_REQUIRE(n_tiles >= 0, "tile_sort: bad n_tiles");
   if (n_tiles == 0) return GSR_OK;
   GSR_REQUIRE(tile_offsets && big_list, "tile_sort: null pointer");
   GSR_CHECK_HIP(hipMemsetAsync(big_list, 0, sizeof(int32_t), (hipStream_t)stream));
-  hipLaunchKernelGGL(gsr::tile_sort_small_kernel, dim3(gsr::xcd_grid(n_tiles)), dim3(256), 0,
-                     (hipStream_t)stream, n_tiles, tile_offsets, isect_keys, flatten_ids, big_list);
+  hipLaunchKernelGGL(gsr::tile_sort_small_kernel, dim3(n_tiles), dim3(256), 0,
+                     (hipStream_t)stream, n_tiles, tile_offsets, tile_order, isect_keys,
+                     flatten_ids, big_list);
   GSR_CHECK_LAUNCH("tile_sort_small");
   hipLaunchKernelGGL(gsr::tile_sort_large_kernel, dim3(256), dim3(1024), 0, (hipStream_t)stream,
                      tile_offsets, isect_keys, flatten_ids, big_list);

@@ -28,6 +28,7 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   int color_stride, const float *__restrict__ opacities, int opac_per_camera,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
+                  const int32_t *__restrict__ tile_order,
                   const int32_t *__restrict__ flatten_ids,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
@@ -38,8 +39,8 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   __shared__ int sId[2][64];
   __shared__ __attribute__((aligned(16))) float sG[64][GSR_GRAD_ROW];  // batch gradient rows
 
-  const int tile = xcd_remap(blockIdx.x, n_tiles);
-  if (tile >= n_tiles) return;
+  if ((int)blockIdx.x >= n_tiles) return;
+  const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   const int tiles_per_cam = tile_w * tile_h;
   const int cam = tile / tiles_per_cam;
   const int tin = tile - cam * tiles_per_cam;
@@ -165,20 +166,22 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
           g_con[0] = fmaf(0.5f * tdx, dx, g_con[0]);
           g_con[1] = fmaf(tdx, dy, g_con[1]);
           g_con[2] = fmaf(0.5f * tdy, dy, g_con[2]);
-          const float vx = fmaf(ca, tdx, cb * tdy);
-          const float vy = fmaf(cb, tdx, cc * tdy);
-          g_xy[0] += vx;
-          g_xy[1] += vy;
+          // v_xy = conic * (sum v_sigma*dx, sum v_sigma*dy): only the two first
+          // moments are summed per pixel, the 2x2 product is applied once after
+          // the reduction (absgrad needs the per-pixel value).
+          g_xy[0] += tdx;
+          g_xy[1] += tdy;
           if (ABSGRAD) {
-            g_abs[0] += fabsf(vx);
-            g_abs[1] += fabsf(vy);
+            g_abs[0] += fabsf(fmaf(ca, tdx, cb * tdy));
+            g_abs[1] += fabsf(fmaf(cb, tdx, cc * tdy));
           }
           g_op = fmaf(vis, va, g_op);
         }
       }
       if (!__any(any_valid)) continue;  // wave-uniform skip
       // row reduction on DPP, then 4 lanes (one per row) add into the LDS row
-      const float r_x = row_sum16(g_xy[0]), r_y = row_sum16(g_xy[1]);
+      const float m_x = row_sum16(g_xy[0]), m_y = row_sum16(g_xy[1]);
+      const float r_x = fmaf(ca, m_x, cb * m_y), r_y = fmaf(cb, m_x, cc * m_y);
       const float r_a = row_sum16(g_con[0]), r_b = row_sum16(g_con[1]), r_c = row_sum16(g_con[2]);
       const float r_o = row_sum16(g_op);
       float r_col[CH];
@@ -231,21 +234,21 @@ static int launch_bwd(int n_tiles, int N, const float *means2d, const float *con
                       const float *colors, int color_stride, const float *opacities,
                       int opac_per_camera, const float *backgrounds, int width, int height,
                       int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *flatten_ids, const float *render_alphas,
+                      const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
                       const int32_t *last_ids, const float *v_render_colors,
                       const float *v_render_alphas, int absgrad, float *grad_rows,
                       hipStream_t stream) {
   if (absgrad)
-    hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(xcd_grid(n_tiles)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), 0, stream,
                        n_tiles, N, means2d, conics, colors, color_stride, opacities,
                        opac_per_camera, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
+                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
                        grad_rows);
   else
-    hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(xcd_grid(n_tiles)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(n_tiles), dim3(64), 0, stream,
                        n_tiles, N, means2d, conics, colors, color_stride, opacities,
                        opac_per_camera, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
+                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
                        grad_rows);
   GSR_CHECK_LAUNCH("rasterize_bwd");
   return GSR_OK;
@@ -257,7 +260,7 @@ extern "C" int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, con
                                  const float *colors, int color_stride, const float *opacities,
                                  int opac_per_camera, const float *backgrounds, int width,
                                  int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                                 const int32_t *flatten_ids, const float *render_alphas,
+                                 const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
                                  const int32_t *last_ids, const float *v_render_colors,
                                  const float *v_render_alphas, int absgrad, float *grad_rows,
                                  void *stream) {
@@ -276,7 +279,7 @@ extern "C" int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, con
   case K:                                                                                     \
     return gsr::launch_bwd<K>(n_tiles, N, means2d, conics, colors, color_stride, opacities,   \
                               opac_per_camera, backgrounds, width, height, tile_w, tile_h,    \
-                              tile_offsets, flatten_ids, render_alphas, last_ids,             \
+                              tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, \
                               v_render_colors, v_render_alphas, absgrad, grad_rows, st);
   switch (CH) {
     GSR_BWD_CASE(1)

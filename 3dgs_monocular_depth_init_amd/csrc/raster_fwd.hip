@@ -7,25 +7,31 @@
 // no cross-wave barriers, wave-uniform early exit). The tile's depth-sorted
 // list is streamed through LDS in batches of 64 Gaussians, double-buffered:
 // the gather of batch k+1 is in flight while batch k is composited.
+#include <type_traits>
+
 #include "raster_common.h"
 
 namespace gsr {
 
 template <int CH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (CH <= 3) ? 8 : 6)
 raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   const float *__restrict__ conics, const float *__restrict__ colors,
                   int color_stride, const float *__restrict__ opacities, int opac_per_camera,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
+                  const int32_t *__restrict__ tile_order,
                   const int32_t *__restrict__ flatten_ids, float *__restrict__ render_colors,
                   float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
   __shared__ float4 sA[2][64];
   __shared__ float4 sB[2][64];
-  __shared__ float4 sC[2][64];
+  // CH <= 3: {col2, quadrant mask}; CH 4,5: {col2, col3, col4, mask}. 5 KB of LDS
+  // per wave at CH <= 3, so 32 waves (8 per SIMD) fit the CU's 160 KB.
+  using CT = typename std::conditional<(CH <= 3), float2, float4>::type;
+  __shared__ CT sC[2][64];
 
-  const int tile = xcd_remap(blockIdx.x, n_tiles);
-  if (tile >= n_tiles) return;
+  if ((int)blockIdx.x >= n_tiles) return;
+  const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   const int tiles_per_cam = tile_w * tile_h;
   const int cam = tile / tiles_per_cam;
   const int tin = tile - cam * tiles_per_cam;
@@ -71,22 +77,23 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
     if (lane < n) {
       sA[buf][lane] = rec.a;
       sB[buf][lane] = rec.b;
-      sC[buf][lane] = rec.c;
+      if constexpr (CH <= 3) sC[buf][lane] = make_float2(rec.c.x, rec.c.w);
+      else sC[buf][lane] = rec.c;
     }
     __syncthreads();
     const int nb = base + 64;
     if (nb + lane < e)
       stage_gauss<CH>(flatten_ids[nb + lane], N, means2d, conics, colors, color_stride,
                       opacities, opac_per_camera, (float)tx0, (float)ty0, rec);
-    float4 A = sA[buf][0], B = sB[buf][0], C4 = sC[buf][0];
     for (int j = 0; j < n; ++j) {
-      // software prefetch of the next record (LDS latency under this Gaussian's math)
-      const int jn = min(j + 1, n - 1);
-      const float4 An = sA[buf][jn], Bn = sB[buf][jn], Cn = sC[buf][jn];
-      const float4 Ac = A, Bc = B, Cc = C4;
-      A = An;
-      B = Bn;
-      C4 = Cn;
+      const float4 Ac = sA[buf][j], Bc = sB[buf][j];
+      float4 Cc;
+      if constexpr (CH <= 3) {
+        const float2 c2 = sC[buf][j];
+        Cc = make_float4(c2.x, 0.f, 0.f, c2.y);
+      } else {
+        Cc = sC[buf][j];
+      }
       const unsigned qm =
           (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(Cc.w)) & live;
       if (qm == 0) continue;
@@ -142,11 +149,11 @@ static int launch_fwd(int n_tiles, int N, const float *means2d, const float *con
                       const float *colors, int color_stride, const float *opacities,
                       int opac_per_camera, const float *backgrounds, int width, int height,
                       int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *flatten_ids, float *render_colors, float *render_alphas,
+                      const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors, float *render_alphas,
                       int32_t *last_ids, hipStream_t stream) {
-  hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(xcd_grid(n_tiles)), dim3(64), 0, stream, n_tiles,
+  hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), 0, stream, n_tiles,
                      N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
-                     backgrounds, width, height, tile_w, tile_h, tile_offsets, flatten_ids,
+                     backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order, flatten_ids,
                      render_colors, render_alphas, last_ids);
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
@@ -158,7 +165,7 @@ extern "C" int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, con
                                  const float *colors, int color_stride, const float *opacities,
                                  int opac_per_camera, const float *backgrounds, int width,
                                  int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                                 const int32_t *flatten_ids, float *render_colors,
+                                 const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors,
                                  float *render_alphas, int32_t *last_ids, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
@@ -177,7 +184,8 @@ extern "C" int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, con
   case K:                                                                                    \
     return gsr::launch_fwd<K>(n_tiles, N, means2d, conics, colors, color_stride, opacities,  \
                               opac_per_camera, backgrounds, width, height, tile_w, tile_h,   \
-                              tile_offsets, flatten_ids, render_colors, render_alphas,       \
+                              tile_offsets, tile_order, flatten_ids, render_colors,          \
+                              render_alphas,                                                  \
                               last_ids, st);
   switch (CH) {
     GSR_FWD_CASE(1)

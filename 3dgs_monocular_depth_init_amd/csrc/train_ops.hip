@@ -1,0 +1,120 @@
+// train_ops.hip -- the step either side of the rasterizer:
+// one fused multi-tensor Adam launch over all Gaussian parameters, replacing
+// the six per-parameter torch.optim.Adam steps of
+// gs_init_compare/runner.py:129-137, 676-679 (7 x 236 MB of HBM traffic at
+// 1M Gaussians: read p,g,m,v, write p,m,v -- streamed once, 16 B per lane).
+#include "common.h"
+
+namespace gsr {
+
+constexpr int ADAM_MAX_TENSORS = 8;
+constexpr int ADAM_ELEMS_PER_BLOCK = 256 * 4 * 4;   // 256 threads x float4 x 4
+
+struct AdamArgs {
+  float *p[ADAM_MAX_TENSORS];
+  const float *g[ADAM_MAX_TENSORS];
+  float *m[ADAM_MAX_TENSORS];
+  float *v[ADAM_MAX_TENSORS];
+  int64_t numel[ADAM_MAX_TENSORS];
+  int32_t block_start[ADAM_MAX_TENSORS + 1];
+  float step_size[ADAM_MAX_TENSORS];      // lr / (1 - beta1^t)
+  float bc2_sqrt[ADAM_MAX_TENSORS];       // sqrt(1 - beta2^t)
+  float beta1, beta2, eps;
+  int n;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float beta1,
+                                         float beta2, float eps, float step_size,
+                                         float bc2_sqrt) {
+  // same operation order as torch.optim.Adam (_single_tensor_adam)
+  m = m + (g - m) * (1.0f - beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * beta2 + (1.0f - beta2) * g * g;            // mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);                   // addcdiv_(exp_avg, denom, -step_size)
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
+  int t = 0;
+  const int b = blockIdx.x;
+#pragma unroll
+  for (int i = 1; i < ADAM_MAX_TENSORS; ++i)
+    if (i < a.n && b >= a.block_start[i]) t = i;
+  const int64_t base = (int64_t)(b - a.block_start[t]) * ADAM_ELEMS_PER_BLOCK;
+  const int64_t n = a.numel[t];
+  float *__restrict__ p = a.p[t];
+  const float *__restrict__ g = a.g[t];
+  float *__restrict__ m = a.m[t];
+  float *__restrict__ v = a.v[t];
+  const float ss = a.step_size[t], bc2 = a.bc2_sqrt[t];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + ((int64_t)r * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+      float4 pp = *reinterpret_cast<float4 *>(p + i);
+      const float4 gg = *reinterpret_cast<const float4 *>(g + i);
+      float4 mm = *reinterpret_cast<float4 *>(m + i);
+      float4 vv = *reinterpret_cast<float4 *>(v + i);
+      adam_one(pp.x, gg.x, mm.x, vv.x, a.beta1, a.beta2, a.eps, ss, bc2);
+      adam_one(pp.y, gg.y, mm.y, vv.y, a.beta1, a.beta2, a.eps, ss, bc2);
+      adam_one(pp.z, gg.z, mm.z, vv.z, a.beta1, a.beta2, a.eps, ss, bc2);
+      adam_one(pp.w, gg.w, mm.w, vv.w, a.beta1, a.beta2, a.eps, ss, bc2);
+      *reinterpret_cast<float4 *>(p + i) = pp;
+      *reinterpret_cast<float4 *>(m + i) = mm;
+      *reinterpret_cast<float4 *>(v + i) = vv;
+    } else {
+      for (int64_t k = i; k < n && k < i + 4; ++k) {
+        float pp = p[k], mm = m[k], vv = v[k];
+        adam_one(pp, g[k], mm, vv, a.beta1, a.beta2, a.eps, ss, bc2);
+        p[k] = pp;
+        m[k] = mm;
+        v[k] = vv;
+      }
+    }
+  }
+}
+
+}  // namespace gsr
+
+// params/grads/exp_avg/exp_avg_sq: HOST arrays of n device pointers (16-byte
+// aligned tensors); numel, step_size (= lr/(1-beta1^t)), bc2_sqrt
+// (= sqrt(1-beta2^t)): HOST arrays of n entries. n <= 8.
+extern "C" int gsr_adam_step(int n, void *const *params, const void *const *grads,
+                             void *const *exp_avg, void *const *exp_avg_sq,
+                             const int64_t *numel, const float *step_size,
+                             const float *bc2_sqrt, float beta1, float beta2, float eps,
+                             void *stream) {
+  GSR_REQUIRE(n >= 0 && n <= gsr::ADAM_MAX_TENSORS, "adam_step: n=%d (max %d)", n,
+              gsr::ADAM_MAX_TENSORS);
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && step_size && bc2_sqrt,
+              "adam_step: null array");
+  gsr::AdamArgs a;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    GSR_REQUIRE(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && numel[i] >= 0,
+                "adam_step: tensor %d has a null pointer", i);
+    GSR_REQUIRE(((uintptr_t)params[i] | (uintptr_t)grads[i] | (uintptr_t)exp_avg[i] |
+                 (uintptr_t)exp_avg_sq[i]) % 16 == 0,
+                "adam_step: tensor %d is not 16-byte aligned", i);
+    a.p[i] = (float *)params[i];
+    a.g[i] = (const float *)grads[i];
+    a.m[i] = (float *)exp_avg[i];
+    a.v[i] = (float *)exp_avg_sq[i];
+    a.numel[i] = numel[i];
+    a.step_size[i] = step_size[i];
+    a.bc2_sqrt[i] = bc2_sqrt[i];
+    a.block_start[i] = blocks;
+    int64_t nb = gsr::ceil_div64(numel[i], gsr::ADAM_ELEMS_PER_BLOCK);
+    GSR_REQUIRE(blocks + nb < 2147483647LL, "adam_step: too many elements");
+    blocks += (int)nb;
+  }
+  a.block_start[n] = blocks;
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.n = n;
+  if (blocks == 0) return GSR_OK;
+  hipLaunchKernelGGL(gsr::adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  GSR_CHECK_LAUNCH("adam_step");
+  return GSR_OK;
+}

@@ -65,6 +65,6 @@ def shard_views(n_views: int, step: int, rank: int, world: int, perm=None) -> in
 
 
 def fuse_optimizers(splats, optimizers: Dict[str, torch.optim.Optimizer]):
-    """Placeholder for the fused multi-tensor Adam; today the six
-    per-parameter torch.optim.Adam instances of the reference are kept."""
-    return optimizers
+    """Wrap the reference's six per-parameter Adam instances in one fused launch."""
+    from .optim import FusedAdam
+    return FusedAdam(optimizers)

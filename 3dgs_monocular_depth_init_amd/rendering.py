@@ -190,18 +190,20 @@ def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride
 @torch.no_grad()
 def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
                        want_tiles_per_gauss: bool = False):
-    """Returns (tile_offsets [n_tiles+1] int32, flatten_ids [I] int32,
-    isect_keys [I] int64 (depth_bits<<32 | g, sorted per tile), tiles_per_gauss or None)."""
+    """Returns (tile_offsets [n_tiles+1] int32, tile_order [n_tiles] int32 (longest list
+    first), flatten_ids [I] int32, isect_keys [I] int64 (depth_bits<<32 | g, sorted per
+    tile), tiles_per_gauss or None)."""
     C, N = depths.shape
     dev = depths.device
     n_tiles = C * tile_w * tile_h
     tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     tpg = torch.empty(C, N, dtype=torch.int32, device=dev) if want_tiles_per_gauss else None
     st = _stream()
     call("gsr_isect_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(tpg),
          ptr(tile_counts), st)
-    call("gsr_isect_scan", n_tiles, ptr(tile_counts), ptr(tile_offsets), st)
+    call("gsr_isect_scan", n_tiles, ptr(tile_counts), ptr(tile_offsets), ptr(tile_order), st)
     n_isects = int(tile_offsets[-1].item())          # the one host sync of the step
     keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
@@ -209,9 +211,9 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
         call("gsr_isect_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
              ptr(tile_offsets), ptr(tile_counts), ptr(keys), n_isects, st)
         big_list = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-        call("gsr_tile_sort", n_tiles, ptr(tile_offsets), ptr(keys), ptr(flatten_ids),
-             ptr(big_list), st)
-    return tile_offsets, flatten_ids[:n_isects], keys[:n_isects], tpg
+        call("gsr_tile_sort", n_tiles, ptr(tile_offsets), ptr(tile_order), ptr(keys),
+             ptr(flatten_ids), ptr(big_list), st)
+    return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], tpg
 
 
 # --------------------------------------------------------------------------- #
@@ -219,8 +221,8 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
 # --------------------------------------------------------------------------- #
 class _Rasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, flatten_ids,
-                cfg):
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order,
+                flatten_ids, cfg):
         width, height, tile_w, tile_h, CH, absgrad = cfg
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
@@ -231,18 +233,18 @@ class _Rasterize(torch.autograd.Function):
         per_cam = int(opacities.dim() == 2)
         call("gsr_rasterize_fwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
              ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
-             ptr(tile_offsets), ptr(flatten_ids), ptr(render_colors), ptr(render_alphas),
-             ptr(last_ids), _stream())
+             ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_colors),
+             ptr(render_alphas), ptr(last_ids), _stream())
         ctx.cfg = cfg
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, tile_offsets,
-                              flatten_ids, render_alphas, last_ids)
+                              tile_order, flatten_ids, render_alphas, last_ids)
         ctx.mark_non_differentiable(last_ids)
         return render_colors, render_alphas, last_ids
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas, _v_last):
         width, height, tile_w, tile_h, CH, absgrad = ctx.cfg
-        (means2d, conics, colors, opacities, backgrounds, tile_offsets, flatten_ids,
+        (means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order, flatten_ids,
          render_alphas, last_ids) = ctx.saved_tensors
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
@@ -257,8 +259,9 @@ class _Rasterize(torch.autograd.Function):
         per_cam = int(opacities.dim() == 2)
         call("gsr_rasterize_bwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
              ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
-             ptr(tile_offsets), ptr(flatten_ids), ptr(render_alphas), ptr(last_ids),
-             ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows), _stream())
+             ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_alphas),
+             ptr(last_ids), ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows),
+             _stream())
         v_means2d = rows[:, GR_MEAN2D:GR_MEAN2D + 2].view(C, N, 2)
         v_conics = rows[:, GR_CONIC:GR_CONIC + 3].view(C, N, 3)
         v_colors = rows[:, GR_COLOR:GR_COLOR + color_stride].view(C, N, color_stride)
@@ -271,7 +274,7 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             T_final = 1.0 - render_alphas
             v_bg = (v_render_colors * T_final).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -397,12 +400,12 @@ def rasterization(
 
     tile_w = math.ceil(width / TILE)
     tile_h = math.ceil(height / TILE)
-    tile_offsets, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
+    tile_offsets, tile_order, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
         means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False)
 
     rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
     render_colors, render_alphas, _last = _Rasterize.apply(
-        means2d, conics, feats, opac, backgrounds, tile_offsets, flatten_ids, rcfg)
+        means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids, rcfg)
 
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat(

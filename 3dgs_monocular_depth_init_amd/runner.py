@@ -165,7 +165,11 @@ def train_step(
     if grad_sync is not None:
         grad_sync()
     if optimizers is not None:
-        for opt in optimizers.values():                                  # runner.py:676-679
-            opt.step()
-            opt.zero_grad(set_to_none=True)
+        if hasattr(optimizers, "step"):                                  # FusedAdam: one launch
+            optimizers.step()
+            optimizers.zero_grad(set_to_none=True)
+        else:
+            for opt in optimizers.values():                              # runner.py:676-679
+                opt.step()
+                opt.zero_grad(set_to_none=True)
     return loss.detach(), info

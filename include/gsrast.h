@@ -96,7 +96,9 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
  * tile ids are c*tile_h*tile_w + ty*tile_w + tx; n_tiles = C*tile_h*tile_w.
  * gsr_isect_count : tile_counts[n_tiles] (zeroed inside) and, optionally,
  *                   tiles_per_gauss[C*N].
- * gsr_isect_scan  : exclusive scan -> tile_offsets[n_tiles+1] (last = n_isects).
+ * gsr_isect_scan  : exclusive scan -> tile_offsets[n_tiles+1] (last = n_isects);
+ *                   optionally tile_order[n_tiles] = tile ids, longest list first
+ *                   (the work order of gsr_rasterize_fwd/bwd).
  * gsr_isect_emit  : scatter (depth_bits<<32 | g) into the tile buckets.
  *                   tile_cursor[n_tiles] is scratch (zeroed inside).
  * gsr_tile_sort   : sort every bucket ascending (depth, then g) in place and
@@ -106,34 +108,53 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
 int gsr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_w,
                     int tile_h, int32_t *tiles_per_gauss /* or NULL */, int32_t *tile_counts,
                     void *stream);
-int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets, void *stream);
+int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets,
+                   int32_t *tile_order /* [n_tiles] or NULL */, void *stream);
 int gsr_isect_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                    int tile_w, int tile_h, const int32_t *tile_offsets, int32_t *tile_cursor,
                    uint64_t *isect_keys, int64_t capacity, void *stream);
-int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets, uint64_t *isect_keys,
+int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
+                  const int32_t *tile_order /* or NULL */, uint64_t *isect_keys,
                   int32_t *flatten_ids, int32_t *big_list /* scratch [n_tiles+1] */,
                   void *stream);
 
 /* ---------------------------------------------------------------------------
- * A6 / A7: alpha compositing, one wave64 per 16x16 tile, 2x2 pixels per lane.
- * opacities is [N] (opac_per_camera = 0) or [C,N] (1). backgrounds [C,CH] or
- * NULL. last_ids [C,H,W] int32 is the flat index (into flatten_ids) of the
- * last Gaussian blended into a pixel, -1 if none.
+ * A6 / A7: alpha compositing, one wave64 per 16x16 tile (four 8x8 quadrants,
+ * one pixel of each per lane). opacities is [N] (opac_per_camera = 0) or
+ * [C,N] (1). backgrounds [C,CH] or NULL. last_ids [C,H,W] int32 is the flat
+ * index (into flatten_ids) of the last Gaussian blended into a pixel, -1 if
+ * none. tile_order (from gsr_isect_scan) is the order workgroups take tiles in;
+ * NULL = natural order.
  * --------------------------------------------------------------------------*/
 int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, const float *conics,
                       const float *colors, int color_stride, const float *opacities,
                       int opac_per_camera, const float *backgrounds, int width, int height,
                       int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *flatten_ids, float *render_colors, float *render_alphas,
-                      int32_t *last_ids, void *stream);
+                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      float *render_colors, float *render_alphas, int32_t *last_ids,
+                      void *stream);
 int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *conics,
                       const float *colors, int color_stride, const float *opacities,
                       int opac_per_camera, const float *backgrounds, int width, int height,
                       int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *flatten_ids, const float *render_alphas,
-                      const int32_t *last_ids, const float *v_render_colors,
+                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      const float *render_alphas, const int32_t *last_ids,
+                      const float *v_render_colors,
                       const float *v_render_alphas, int absgrad,
                       float *grad_rows /* [C*N,16], zeroed by caller, accumulated */, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * A8 / F2: fused multi-tensor Adam over the Gaussian parameters, one launch
+ * for all tensors (replaces the six torch.optim.Adam steps of
+ * gs_init_compare/runner.py:129-137, 676-679; same update as
+ * torch.optim.Adam without weight decay / amsgrad). The pointer arrays and the
+ * per-tensor scalars are HOST arrays of n <= 8 entries; the tensors they point
+ * to are device memory, 16-byte aligned. step_size[i] = lr_i / (1 - beta1^t_i),
+ * bc2_sqrt[i] = sqrt(1 - beta2^t_i).
+ * --------------------------------------------------------------------------*/
+int gsr_adam_step(int n, void *const *params, const void *const *grads, void *const *exp_avg,
+                  void *const *exp_avg_sq, const int64_t *numel, const float *step_size,
+                  const float *bc2_sqrt, float beta1, float beta2, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud).
