@@ -35,6 +35,20 @@ SIGNATURES = {
                           _p, _p, _p, _i, _p, _p],
 }
 SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]
+SIGNATURES.update({
+    "gsr_project_sfm": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],
+    "gsr_gather_depth": [_i, _p, _i, _p, _p, _p],
+    "gsr_lsq_sums": [_i, _i, _i, _p, _p, _p, _i, _p, _f, _p, _p],
+    "gsr_solve_scale_shift": [_i, _p, _p, _p],
+    "gsr_ransac_score": [_i, _i, _p, _p, _p, _f, _p, _p, _p, _p],
+    "gsr_affine_depth": [_i64, _p, _p, _p, _p],
+    "gsr_subsample_mask": [_i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p],
+    "gsr_sfm_patch_mask": [_i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "gsr_depth_grad": [_i, _i, _p, _p, _p],
+    "gsr_unproject_num_blocks": [_i, _i],
+    "gsr_unproject_count": [_i, _i, _p, _p, _p, _p, _p, _p],
+    "gsr_unproject_emit": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+})
 OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)
 
 

@@ -157,57 +157,66 @@ int gsr_adam_step(int n, void *const *params, const void *const *grads, void *co
                   const float *bc2_sqrt, float beta1, float beta2, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------
- * Init path (monocular depth -> seed point cloud).
+ * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.
+ * coords arrays are int64 [2,M], row 0 = x, row 1 = y (the reference's
+ * sfm_points_camera_coords). Masks are uint8 (0/1) [H*W].
  * --------------------------------------------------------------------------*/
-/* B2: normal-equation sums of d=(depth,1), g over M samples gathered from the
- * depth map at integer (x,y) coords. sums_out[5] (fp64, device) =
- * {sum d^2, sum d, M, sum d*g, sum g}. coords is [2,M] int64 (row 0 = x). */
-int gsr_lstsq_sums(int M, const float *depth_map, int depth_w, const int64_t *coords,
-                   const float *gt, double *sums_out, void *stream);
-/* Gather depth_map[y,x] at coords -> out[M]. */
+/* B1 (points_from_depth.py:111-180): project M SfM points with P [3,4],
+ * round half-to-even to integer pixels, inbounds[i] = in image && z >= 0,
+ * valid[i] = inbounds && pred_mask[y,x]; coords of out-of-bounds points are
+ * zeroed as in the reference. depth_out[i] = z. */
+int gsr_project_sfm(int M, const float *pts /* [M,3] */, const float *P, int W, int H,
+                    const uint8_t *pred_mask, int64_t *coords, float *depth_out,
+                    uint8_t *inbounds, uint8_t *valid, void *stream);
+/* out[i] = depth_map[y_i, x_i]. */
 int gsr_gather_depth(int M, const float *depth_map, int depth_w, const int64_t *coords,
                      float *out, void *stream);
-/* B3: score T hypotheses (scale,shift)[T,2] against M correspondences in one
- * launch: squared residual r = (s*d+t-g)^2; out_ransac[T] = #(r >= thr)
- * (int32), out_msac[T] = sum min(r,thr) (fp32), out_inliers[T] = #(r < thr). */
+/* B2/B3: normal-equation sums of (d,1) against g (lstsqrs.py:22-25) for T
+ * subsets of the M correspondences, fp64: sums_out[T,5] = {sum d^2, sum d,
+ * count, sum d*g, sum g}. mode 0: all M (T = 1); mode 1: the S sample indices
+ * sample_idx[T,S]; mode 2: the inliers ((s*d+t-g)^2 < thr) of hyp[T,2]. */
+int gsr_lsq_sums(int T, int M, int mode, const float *d, const float *g,
+                 const int64_t *sample_idx, int S, const float *hyp, float thr, double *sums_out,
+                 void *stream);
+/* hyp[T,2] = pinv([[Sdd,Sd],[Sd,n]]) @ [Sdg,Sg]  (scale, shift), fp64 -> fp32. */
+int gsr_solve_scale_shift(int T, const double *sums, float *hyp, void *stream);
+/* B3 (ransacs.py:60-65, 94-97): squared residuals of T hypotheses over all M
+ * in one launch: out_ransac[T] = #(r >= thr), out_msac[T] = sum min(r, thr),
+ * out_inliers[T] = #(r < thr). */
 int gsr_ransac_score(int T, int M, const float *hyp, const float *d, const float *g, float thr,
                      int32_t *out_ransac, float *out_msac, int32_t *out_inliers, void *stream);
-/* Inlier-restricted normal-equation sums for T hypotheses: sums_out[T,5] fp64. */
-int gsr_ransac_lo_sums(int T, int M, const float *hyp, const float *d, const float *g, float thr,
-                       double *sums_out, void *stream);
-/* aligned = depth*scale + shift over H*W (scale/shift read from device hs[2]). */
+/* aligned = depth*hs[0] + hs[1] (two rounded fp32 ops), hs on the device. */
 int gsr_affine_depth(int64_t n, const float *depth, const float *hs, float *out, void *stream);
 
-/* B5/B6: per-pixel subsampling factor map. mode 0: static factor k.
- * mode 1: adaptive (lo/hi = IQR-clipped range read from device range[2]),
- * factor = trunc(clamp(fmin + (fmax-fmin)*(1-clamp((d-lo)/(hi-lo),0,1)))),
- * invalid pixels use multiplier 0.5. Writes keep[H*W] (uint8):
- * y%f==0 && x%f==0 && valid. */
+/* B5/B6: keep[i] = y%f==0 && x%f==0 && valid[i]. mode 0: f = static_k
+ * (static_subsampler.py:8-22). mode 1 (adaptive_subsampling.py:89-122):
+ * m = 1 - clamp((d-lo)/(hi-lo),0,1) (0.5 where !valid), f = trunc(clamp(fmin +
+ * (fmax-fmin)*m, fmin, fmax)), lo/hi = range[0..1] on the device. */
 int gsr_subsample_mask(int H, int W, int mode, int static_k, const float *depth,
                        const uint8_t *valid, const float *range, int fmin, int fmax,
                        uint8_t *keep, void *stream);
-/* B7: patch-density mask: patch_counts[gh*gw] (zeroed inside) histogram of
- * SfM points, mask[H*W] = 0 where its patch holds > threshold points. */
+/* B7 (num_sfm_points_mask.py:38-64): patch_counts[gh*gw] (zeroed inside) =
+ * histogram of the M points over patches of (ph,pw) pixels; mask[i] = 0 where
+ * the pixel's patch holds > threshold points. */
 int gsr_sfm_patch_mask(int H, int W, int M, const int64_t *coords, int ph, int pw, int gh,
-                       int gw, int threshold, int32_t *patch_counts, uint8_t *mask,
-                       void *stream);
-/* B8: depth-gradient mask (|dx|+|dy| forward differences, min-max normalised). */
+                       int gw, int threshold, int32_t *patch_counts, uint8_t *mask, void *stream);
+/* B8 (points_from_depth.py:203-208): |dx| + |dy| backward differences. */
 int gsr_depth_grad(int H, int W, const float *depth, float *grad, void *stream);
-/* B9: fused mask -> stream compaction -> unprojection.
- * keep = subsample[i] & valid[i] & (depth[i] >= 0) [& extra[i]].
- * Pass 1 (gsr_unproject_count) writes block_counts; the caller scans them
- * with gsr_isect_scan; pass 2 writes pts[n,3], rgb_out[n,3] in pixel order
- * (identical to boolean-mask indexing) and final_mask[H*W].
- * Kinv [3,3], c2w [4,4] device pointers. */
+/* B9 (points_from_depth.py:270-312): fused mask -> ordered stream compaction ->
+ * unprojection. keep = valid & subsample & (depth >= 0) [& extra].
+ * gsr_unproject_count writes block_counts[gsr_unproject_num_blocks(H,W)];
+ * the caller scans them with gsr_isect_scan; gsr_unproject_emit then writes
+ * pts[n,3] (world), rgb_out[n,3] (optional) in pixel order -- identical to
+ * boolean-mask indexing -- and final_mask[H*W] (optional). Kinv [3,3],
+ * c2w [4,4] are device pointers. */
+int gsr_unproject_num_blocks(int H, int W);
 int gsr_unproject_count(int H, int W, const float *depth, const uint8_t *valid,
                         const uint8_t *subsample, const uint8_t *extra, int32_t *block_counts,
-                        int *n_blocks_out_host, void *stream);
+                        void *stream);
 int gsr_unproject_emit(int H, int W, const float *depth, const uint8_t *valid,
                        const uint8_t *subsample, const uint8_t *extra, const float *rgb,
                        const float *Kinv, const float *c2w, const int32_t *block_offsets,
                        float *pts, float *rgb_out, uint8_t *final_mask, void *stream);
-/* Number of compaction blocks gsr_unproject_count uses for an H x W image. */
-int gsr_unproject_num_blocks(int H, int W);
 
 #ifdef __cplusplus
 }

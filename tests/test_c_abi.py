@@ -1,0 +1,62 @@
+"""CPU checks of the drop-in boundary: libgsrast.so loads without a GPU and
+exports every symbol include/gsrast.h declares; the ctypes table covers them."""
+import ctypes
+import importlib
+import re
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared():
+    text = (ROOT / "include" / "gsrast.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
+    pkg.build()
+    lib = pkg._lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in gsrast.h but not exported"
+    assert lib.gsr_arch().decode() == "gfx950"
+    assert lib.gsr_version() >= 1
+
+
+def test_ctypes_table_matches_header():
+    pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
+    table = set(pkg._lib.SIGNATURES) | {"gsr_version", "gsr_last_error", "gsr_arch"}
+    assert set(_declared()) == table
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
+    lib = pkg._lib.load()
+    rc = lib.gsr_rasterize_fwd(1, 1, 9, *([None] * 3), 9, None, 0, None, 16, 16, 1, 1,
+                               *([None] * 7))
+    assert rc == -1 and b"CH=9" in lib.gsr_last_error()
+    import pytest
+    with pytest.raises(pkg._lib.GsrastError):
+        pkg._lib.call("gsr_isect_scan", -1, None, None, None, None)
+
+
+def test_product_has_no_oracle_or_cpu_fallback():
+    """The package must not import the oracle (parity rule) and must refuse CPU tensors."""
+    import torch
+    pkg_dir = ROOT / "3dgs_monocular_depth_init_amd"
+    for py in pkg_dir.rglob("*.py"):
+        src = py.read_text()
+        assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# ", ""), py
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    import pytest
+    with pytest.raises(pkg_err()):
+        R.rasterization(torch.zeros(1, 3), torch.ones(1, 4), torch.ones(1, 3), torch.ones(1),
+                        torch.zeros(1, 1, 3), torch.eye(4)[None], torch.eye(3)[None], 16, 16,
+                        sh_degree=0)
+
+
+def pkg_err():
+    return importlib.import_module("3dgs_monocular_depth_init_amd._lib").GsrastError
