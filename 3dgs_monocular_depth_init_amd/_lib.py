@@ -34,7 +34,7 @@ SIGNATURES = {
     "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
                           _p, _p, _p, _i, _p, _p],
 }
-SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p]
+SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES.update({
     "gsr_project_sfm": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],
     "gsr_gather_depth": [_i, _p, _i, _p, _p, _p],

@@ -20,15 +20,16 @@ struct AdamArgs {
   float step_size[ADAM_MAX_TENSORS];      // lr / (1 - beta1^t)
   float bc2_sqrt[ADAM_MAX_TENSORS];       // sqrt(1 - beta2^t)
   float beta1, beta2, eps;
+  float omb1, omb2;                        // 1-beta1, 1-beta2 rounded from fp64 (as torch does)
   int n;
 };
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float beta1,
-                                         float beta2, float eps, float step_size,
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1,
+                                         float beta2, float omb2, float eps, float step_size,
                                          float bc2_sqrt) {
   // same operation order as torch.optim.Adam (_single_tensor_adam)
-  m = m + (g - m) * (1.0f - beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * beta2 + (1.0f - beta2) * g * g;            // mul_(beta2).addcmul_(g, g, 1 - beta2)
+  m = m + (g - m) * omb1;                            // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * beta2 + omb2 * g * g;                      // mul_(beta2).addcmul_(g, g, 1 - beta2)
   const float denom = sqrtf(v) / bc2_sqrt + eps;
   p = p - step_size * (m / denom);                   // addcdiv_(exp_avg, denom, -step_size)
 }
@@ -54,17 +55,17 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
       const float4 gg = *reinterpret_cast<const float4 *>(g + i);
       float4 mm = *reinterpret_cast<float4 *>(m + i);
       float4 vv = *reinterpret_cast<float4 *>(v + i);
-      adam_one(pp.x, gg.x, mm.x, vv.x, a.beta1, a.beta2, a.eps, ss, bc2);
-      adam_one(pp.y, gg.y, mm.y, vv.y, a.beta1, a.beta2, a.eps, ss, bc2);
-      adam_one(pp.z, gg.z, mm.z, vv.z, a.beta1, a.beta2, a.eps, ss, bc2);
-      adam_one(pp.w, gg.w, mm.w, vv.w, a.beta1, a.beta2, a.eps, ss, bc2);
+      adam_one(pp.x, gg.x, mm.x, vv.x, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
+      adam_one(pp.y, gg.y, mm.y, vv.y, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
+      adam_one(pp.z, gg.z, mm.z, vv.z, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
+      adam_one(pp.w, gg.w, mm.w, vv.w, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
       *reinterpret_cast<float4 *>(p + i) = pp;
       *reinterpret_cast<float4 *>(m + i) = mm;
       *reinterpret_cast<float4 *>(v + i) = vv;
     } else {
       for (int64_t k = i; k < n && k < i + 4; ++k) {
         float pp = p[k], mm = m[k], vv = v[k];
-        adam_one(pp, g[k], mm, vv, a.beta1, a.beta2, a.eps, ss, bc2);
+        adam_one(pp, g[k], mm, vv, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
         p[k] = pp;
         m[k] = mm;
         v[k] = vv;
@@ -81,8 +82,9 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
 extern "C" int gsr_adam_step(int n, void *const *params, const void *const *grads,
                              void *const *exp_avg, void *const *exp_avg_sq,
                              const int64_t *numel, const float *step_size,
-                             const float *bc2_sqrt, float beta1, float beta2, float eps,
+                             const float *bc2_sqrt, double beta1_d, double beta2_d, double eps_d,
                              void *stream) {
+  const float beta1 = (float)beta1_d, beta2 = (float)beta2_d, eps = (float)eps_d;
   GSR_REQUIRE(n >= 0 && n <= gsr::ADAM_MAX_TENSORS, "adam_step: n=%d (max %d)", n,
               gsr::ADAM_MAX_TENSORS);
   if (n == 0) return GSR_OK;
@@ -112,6 +114,8 @@ extern "C" int gsr_adam_step(int n, void *const *params, const void *const *grad
   a.beta1 = beta1;
   a.beta2 = beta2;
   a.eps = eps;
+  a.omb1 = (float)(1.0 - (double)beta1_d);
+  a.omb2 = (float)(1.0 - (double)beta2_d);
   a.n = n;
   if (blocks == 0) return GSR_OK;
   hipLaunchKernelGGL(gsr::adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -34,6 +34,14 @@ def _st():
 
 
 def _required_samples(inlier_count, total, min_sample_size, confidence):   # ransacs.py:79-91
+    """k = log(eta) / log(1 - eps^m). In the reference `inlier_count` is a 0-dim
+    int64 TENSOR once a hypothesis has been accepted (ransacs.py:150), so the
+    ratio, its power and `1 - x` are evaluated in fp32: for inlier ratios below
+    ~1.6 % `1 - ratio**4` rounds to 1.0, log() is 0, the ZeroDivisionError branch
+    returns 0 and the loop stops at once. That behaviour is part of the
+    reference's results, so the same expression is evaluated on a CPU tensor."""
+    if not isinstance(inlier_count, torch.Tensor):
+        inlier_count = torch.tensor(int(inlier_count)) if inlier_count else 0
     inlier_ratio = inlier_count / total
     try:
         return math.log(1 - confidence) / math.log(1 - inlier_ratio ** min_sample_size)
@@ -83,6 +91,7 @@ def _align_depth_ransac_generic(predicted_depth, gt_points_camera_coords, gt_dep
     iteration = -1
     done = False
     base = 0
+    required = 0          # _required_samples(0, ...) == 0: ZeroDivisionError branch
     while base < p.max_iters and not done:
         T = min(CHUNK, p.max_iters - base)
         rng_state = torch.get_rng_state()
@@ -99,8 +108,9 @@ def _align_depth_ransac_generic(predicted_depth, gt_points_camera_coords, gt_dep
                     loss_best_lo = ll[k]
                     loss_best_sample = ls[k]
                     num_inliers_best_lo = lin[k]
-            if (_required_samples(num_inliers_best_lo, num_samples, p.sample_size, p.confidence)
-                    <= iteration and h_best_lo is not None and iteration >= p.min_iters):
+                    required = _required_samples(num_inliers_best_lo, num_samples, p.sample_size,
+                                                 p.confidence)
+            if required <= iteration and h_best_lo is not None and iteration >= p.min_iters:
                 done = True
                 if k + 1 < T:      # leave the global RNG where the reference would
                     torch.set_rng_state(rng_state)

@@ -154,7 +154,7 @@ int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *c
  * --------------------------------------------------------------------------*/
 int gsr_adam_step(int n, void *const *params, const void *const *grads, void *const *exp_avg,
                   void *const *exp_avg_sq, const int64_t *numel, const float *step_size,
-                  const float *bc2_sqrt, float beta1, float beta2, float eps, void *stream);
+                  const float *bc2_sqrt, double beta1, double beta2, double eps, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.

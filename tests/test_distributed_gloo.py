@@ -1,0 +1,106 @@
+"""World-size-2 CPU (gloo) tests of the view-parallel path: camera sharding,
+gradient all-reduce (sum), and replica consistency after identical Adam steps.
+The data path has exactly one collective (the gradient all-reduce)."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+        torch.manual_seed(0)                                   # identical replicas
+        N = 257
+        shapes = {"means": (N, 3), "scales": (N, 3), "quats": (N, 4), "opacities": (N,),
+                  "sh0": (N, 1, 3), "shN": (N, 15, 3)}
+        splats = torch.nn.ParameterDict({k: torch.nn.Parameter(torch.randn(s)) for k, s in shapes.items()})
+        opts = {k: torch.optim.Adam([splats[k]], lr=1e-2) for k in splats}
+        sync = D.GradSync(splats, world)
+        cams = []
+        for step in range(3):
+            cams.append(D.shard_views(100, step, rank, world))
+            g = torch.Generator().manual_seed(1000 * step + rank)  # rank-dependent "view" gradient
+            for k, p in splats.items():
+                p.grad = torch.randn(p.shape, generator=g)
+            local = {k: p.grad.clone() for k, p in splats.items()}
+            sync()
+            # expected = sum over ranks of each rank's local gradient
+            for k, p in splats.items():
+                exp = torch.zeros_like(p)
+                for r in range(world):
+                    gr = torch.Generator().manual_seed(1000 * step + r)
+                    for kk, pp in splats.items():
+                        t = torch.randn(pp.shape, generator=gr)
+                        if kk == k:
+                            exp += t
+                assert torch.allclose(p.grad, exp, atol=1e-6), (k, step)
+            for o in opts.values():
+                o.step()
+        flat = torch.cat([p.detach().reshape(-1) for p in splats.values()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(gathered[0], x) for x in gathered), "replicas diverged"
+        q.put((rank, cams, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_allreduce_and_replica_consistency_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort()
+    assert all(r[2] == "ok" for r in res), res
+    # view sharding: step k -> cameras (k*W + r) % n; disjoint across ranks per step
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3, 5]
+
+
+def test_shard_views_covers_dataset():
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    seen = set()
+    for step in range(25):
+        for r in range(4):
+            seen.add(D.shard_views(100, step, r, 4))
+    assert seen == set(range(100))
+    perm = list(reversed(range(10)))
+    assert D.shard_views(10, 0, 1, 2, perm) == 8
+
+
+def test_lr_scaling_rule_matches_reference():
+    """runner.py:128-137: lr*sqrt(BS), eps/sqrt(BS), betas 1-BS(1-b)."""
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    pts = torch.rand(10, 3)
+    splats, opts = R.create_splats_with_optimizers(pts, torch.rand(10, 3), torch.zeros(10, 3),
+                                                   device="cpu", world_size=4, batch_size=1)
+    g = opts["means"].param_groups[0]
+    assert g["lr"] == pytest.approx(1.6e-4 * 2.0)
+    assert g["eps"] == pytest.approx(1e-15 / 2.0)
+    assert g["betas"] == (pytest.approx(1 - 4 * 0.1), pytest.approx(1 - 4 * 0.001))
+    assert opts["shN"].param_groups[0]["lr"] == pytest.approx(2.5e-3 / 20 * 2.0)
+    assert set(splats.keys()) == {"means", "scales", "quats", "opacities", "sh0", "shN"}
+    assert splats["sh0"].shape == (10, 1, 3) and splats["shN"].shape == (10, 15, 3)

@@ -49,8 +49,9 @@ def test_fused_adam_matches_torch(BS):
         a, b = ps_f[k].detach(), ps_ref[k].detach()
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), f"{k}: {float((a - b).abs().max())}"
         sa, sb = opts_f[k].state[ps_f[k]], opts_ref[k].state[ps_ref[k]]
-        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-12)
-        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+        for key in ("exp_avg", "exp_avg_sq"):
+            x, y = sa[key], sb[key]
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max())), key
         assert float(sa["step"]) == float(sb["step"]) == 5
 
 
