@@ -22,9 +22,9 @@ _i64 = C.c_int64
 # name -> argtypes; every function returns int except the three below.
 SIGNATURES = {
     "gsr_project_fwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i,
-                        _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+                        _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _p],
     "gsr_project_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p, _p,
-                        _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+                        _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p],
     "gsr_isect_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p],
     "gsr_isect_scan": [_i, _p, _p, _p, _p],
     "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
@@ -34,6 +34,7 @@ SIGNATURES = {
     "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
                           _p, _p, _p, _i, _p, _p],
 }
+SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p]
 SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES.update({
     "gsr_project_sfm": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p],

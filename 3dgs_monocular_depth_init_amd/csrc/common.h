@@ -68,6 +68,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float,
                             __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Tile rectangle [x0,x1) x [y0,y1) a projected Gaussian touches (A.3): mean +- radius in
+// tile units, clamped to the grid. false = culled / touches nothing.
+__device__ __forceinline__ bool tile_rect_v(float mean_x, float mean_y, int rx, int ry, int tile_w,
+                                            int tile_h, int &x0, int &x1, int &y0, int &y1) {
+  if (rx <= 0 || ry <= 0) return false;
+  const float inv = 1.0f / (float)GSR_TILE;
+  const float mx = mean_x * inv, my = mean_y * inv;
+  const float trx = (float)rx * inv, try_ = (float)ry * inv;
+  x0 = min(max(0, (int)floorf(mx - trx)), tile_w);
+  x1 = min(max(0, (int)ceilf(mx + trx)), tile_w);
+  y0 = min(max(0, (int)floorf(my - try_)), tile_h);
+  y1 = min(max(0, (int)ceilf(my + try_)), tile_h);
+  return (x1 > x0) && (y1 > y0);
+}
+__device__ __forceinline__ bool tile_rect(const float *__restrict__ means2d,
+                                          const int32_t *__restrict__ radii, int64_t g,
+                                          int tile_w, int tile_h, int &x0, int &x1, int &y0,
+                                          int &y1) {
+  return tile_rect_v(means2d[g * 2], means2d[g * 2 + 1], radii[g * 2], radii[g * 2 + 1], tile_w,
+                     tile_h, x0, x1, y0, y1);
+}
+
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {

@@ -12,22 +12,6 @@
 
 namespace gsr {
 
-__device__ __forceinline__ bool tile_rect(const float *__restrict__ means2d,
-                                          const int32_t *__restrict__ radii, int64_t g,
-                                          int tile_w, int tile_h, int &x0, int &x1, int &y0,
-                                          int &y1) {
-  int rx = radii[g * 2 + 0], ry = radii[g * 2 + 1];
-  if (rx <= 0 || ry <= 0) return false;
-  const float inv = 1.0f / (float)GSR_TILE;
-  float mx = means2d[g * 2 + 0] * inv, my = means2d[g * 2 + 1] * inv;
-  float trx = (float)rx * inv, try_ = (float)ry * inv;
-  x0 = min(max(0, (int)floorf(mx - trx)), tile_w);
-  x1 = min(max(0, (int)ceilf(mx + trx)), tile_w);
-  y0 = min(max(0, (int)floorf(my - try_)), tile_h);
-  y1 = min(max(0, (int)ceilf(my + try_)), tile_h);
-  return (x1 > x0) && (y1 > y0);
-}
-
 __global__ void __launch_bounds__(256)
 isect_count_kernel(int C, int N, const float *__restrict__ means2d,
                    const int32_t *__restrict__ radii, int tile_w, int tile_h,

@@ -23,7 +23,9 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    const float *__restrict__ shN, int shN_stride, int32_t *__restrict__ radii,
                    float *__restrict__ means2d, float *__restrict__ depths,
                    float *__restrict__ conics, float *__restrict__ compensations,
-                   float *__restrict__ colors_out, int color_stride, int depth_channel) {
+                   float *__restrict__ colors_out, int color_stride, int depth_channel,
+                   int activations, float *__restrict__ opacities_out, int tile_w, int tile_h,
+                   int32_t *__restrict__ tile_counts) {
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
   int c = (int)(g / N);
@@ -33,6 +35,16 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
   float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
   float opac = opacities ? opacities[i] : -1.f;
+  // A1 fused (runner.py:324-325): scales = exp(raw), opacities = sigmoid(raw)
+  if (activations & GSR_ACT_EXP_SCALES) {
+    s[0] = expf(s[0]);
+    s[1] = expf(s[1]);
+    s[2] = expf(s[2]);
+  }
+  if ((activations & GSR_ACT_SIGMOID_OPAC) && opacities) {
+    opac = 1.0f / (1.0f + expf(-opac));
+    if (c == 0 && opacities_out) opacities_out[i] = opac;
+  }
   gs::Mat3 covar = gs::quat_scale_to_covar(q, s);
   gs::Proj p = gs::project_ewa(cam, mean, covar, opac, width, height, eps2d, near_plane,
                                far_plane, radius_clip, calc_comp != 0);
@@ -45,6 +57,14 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   conics[g * 3 + 1] = p.cb;
   conics[g * 3 + 2] = p.cc;
   if (compensations) compensations[g] = p.comp;
+  if (tile_counts) {   // A5 count pass fused here: its atomics overlap this kernel's streaming
+    int x0, x1, y0, y1;
+    if (tile_rect_v(p.mx, p.my, p.rx, p.ry, tile_w, tile_h, x0, x1, y0, y1)) {
+      int32_t *tc = tile_counts + (int64_t)c * tile_w * tile_h;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) atomicAdd(&tc[y * tile_w + x], 1);
+    }
+  }
   if (!colors_out) return;
   float *co = colors_out + g * color_stride;
   if (sh_degree >= 0) {
@@ -82,12 +102,19 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    const float *__restrict__ v_depths, const float *__restrict__ v_comps,
                    int depth_channel, float *__restrict__ v_means, float *__restrict__ v_quats,
                    float *__restrict__ v_scales, float *__restrict__ v_sh0, int v_sh0_stride,
-                   float *__restrict__ v_shN, int v_shN_stride, int sh_K) {
+                   float *__restrict__ v_shN, int v_shN_stride, int sh_K, int activations,
+                   const float *__restrict__ opacities_act, float *__restrict__ v_opacities) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
   float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
   float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+  if (activations & GSR_ACT_EXP_SCALES) {
+    s[0] = expf(s[0]);
+    s[1] = expf(s[1]);
+    s[2] = expf(s[2]);
+  }
+  float v_op = 0.f;
   gs::Mat3 covar = gs::quat_scale_to_covar(q, s);
   float v_mean[3] = {0.f, 0.f, 0.f};
   gs::Mat3 v_covar = gs::mat3_zero();
@@ -99,6 +126,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     int64_t g = (int64_t)c * N + i;
     if (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) continue;
     const float *row = grad_rows + g * GSR_GRAD_ROW;
+    v_op += row[GSR_GR_OPAC];
     float v_m2d[2] = {row[GSR_GR_MEAN2D], row[GSR_GR_MEAN2D + 1]};
     float v_con[3] = {row[GSR_GR_CONIC], row[GSR_GR_CONIC + 1], row[GSR_GR_CONIC + 2]};
     float v_depth = 0.f;
@@ -156,9 +184,21 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   v_quats[i * 4 + 1] = v_q[1];
   v_quats[i * 4 + 2] = v_q[2];
   v_quats[i * 4 + 3] = v_q[3];
+  if (activations & GSR_ACT_EXP_SCALES) {   // d exp(x) = exp(x)
+    v_s[0] *= s[0];
+    v_s[1] *= s[1];
+    v_s[2] *= s[2];
+  }
   v_scales[i * 3 + 0] = v_s[0];
   v_scales[i * 3 + 1] = v_s[1];
   v_scales[i * 3 + 2] = v_s[2];
+  if (v_opacities) {                         // sum over cameras of the compositing gradient
+    if (activations & GSR_ACT_SIGMOID_OPAC) {
+      const float o = opacities_act[i];
+      v_op *= o * (1.0f - o);
+    }
+    v_opacities[i] = v_op;
+  }
   if (v_sh0) {
     float *o0 = v_sh0 + (int64_t)i * v_sh0_stride;
     o0[0] = v_coef[0][0];
@@ -186,7 +226,9 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
                                int sh_degree, const float *sh0, int sh0_stride, const float *shN,
                                int shN_stride, int32_t *radii, float *means2d, float *depths,
                                float *conics, float *compensations, float *colors_out,
-                               int color_stride, int depth_channel, void *stream) {
+                               int color_stride, int depth_channel, int activations,
+                               float *opacities_out, int tile_w, int tile_h,
+                               int32_t *tile_counts, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "project_fwd: bad sizes C=%d N=%d %dx%d",
               C, N, width, height);
   if ((int64_t)C * N == 0) return GSR_OK;
@@ -201,6 +243,13 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
   if (colors_out)
     GSR_REQUIRE(depth_channel < color_stride, "project_fwd: depth_channel %d >= stride %d",
                 depth_channel, color_stride);
+  GSR_REQUIRE(!(activations & GSR_ACT_SIGMOID_OPAC) || (opacities && opacities_out),
+              "project_fwd: sigmoid activation needs opacities and opacities_out");
+  if (tile_counts) {
+    GSR_REQUIRE(tile_w > 0 && tile_h > 0, "project_fwd: fused tile count needs the tile grid");
+    GSR_CHECK_HIP(hipMemsetAsync(tile_counts, 0, sizeof(int32_t) * (int64_t)C * tile_w * tile_h,
+                                 (hipStream_t)stream));
+  }
   int64_t total = (int64_t)C * N;
   GSR_REQUIRE(total / 256 + 1 < 2147483647LL, "project_fwd: C*N too large");
   dim3 grid((unsigned)gsr::ceil_div64(total, 256));
@@ -208,7 +257,8 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
                      quats, scales, opacities, viewmats, Ks, campos, width, height, eps2d,
                      near_plane, far_plane, radius_clip, calc_compensations, sh_degree, sh0,
                      sh0_stride, shN, shN_stride, radii, means2d, depths, conics, compensations,
-                     colors_out, color_stride, colors_out ? depth_channel : -1);
+                     colors_out, color_stride, colors_out ? depth_channel : -1, activations,
+                     opacities_out, tile_w, tile_h, tile_counts);
   GSR_CHECK_LAUNCH("project_fwd");
   return GSR_OK;
 }
@@ -222,7 +272,8 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
                                const float *v_depths, const float *v_compensations,
                                int depth_channel, float *v_means, float *v_quats,
                                float *v_scales, float *v_sh0, int v_sh0_stride, float *v_shN,
-                               int v_shN_stride, int sh_K, void *stream) {
+                               int v_shN_stride, int sh_K, int activations,
+                               const float *opacities_act, float *v_opacities, void *stream) {
   (void)conics;
   (void)compensations;
   GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd: bad sizes");
@@ -236,12 +287,15 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
                     (sh_degree + 1) * (sh_degree + 1) <= sh_K,
                 "project_bwd: SH arguments inconsistent");
   GSR_REQUIRE(depth_channel < 5, "project_bwd: depth_channel out of range");
+  GSR_REQUIRE(!(activations & GSR_ACT_SIGMOID_OPAC) || !v_opacities || opacities_act,
+              "project_bwd: sigmoid chain rule needs the activated opacities");
   dim3 grid((unsigned)gsr::ceil_div(N, 256));
   hipLaunchKernelGGL(gsr::project_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
                      quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree, sh0,
                      sh0_stride, shN, shN_stride, radii, grad_rows, v_depths, v_compensations,
                      depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
-                     v_sh0_stride, v_shN, v_shN_stride, sh_K);
+                     v_sh0_stride, v_shN, v_shN_stride, sh_K, activations, opacities_act,
+                     v_opacities);
   GSR_CHECK_LAUNCH("project_bwd");
   return GSR_OK;
 }

@@ -74,7 +74,54 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   }
 }
 
+// Batched 4x4 inverse (adjugate / determinant, fp64 inside): replaces the
+// rocSOLVER LU pipeline torch.linalg.inv launches (~14 tiny kernels, ~50 us)
+// for `viewmats = inv(camtoworlds)` (runner.py:347) and for the camera
+// positions the SH view directions need.
+__global__ void inverse4x4_kernel(int C, const float *__restrict__ in, float *__restrict__ out,
+                                  float *__restrict__ in_translation) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double m[16], inv[16];
+  for (int k = 0; k < 16; ++k) m[k] = in[c * 16 + k];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const double idet = 1.0 / det;
+  for (int k = 0; k < 16; ++k) out[c * 16 + k] = (float)(inv[k] * idet);
+  if (in_translation) {
+    in_translation[c * 3 + 0] = in[c * 16 + 3];
+    in_translation[c * 3 + 1] = in[c * 16 + 7];
+    in_translation[c * 3 + 2] = in[c * 16 + 11];
+  }
+}
+
 }  // namespace gsr
+
+extern "C" int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation,
+                              void *stream) {
+  GSR_REQUIRE(C >= 0, "inverse4x4: bad C");
+  if (C == 0) return GSR_OK;
+  GSR_REQUIRE(in && out, "inverse4x4: null pointer");
+  hipLaunchKernelGGL(gsr::inverse4x4_kernel, dim3(gsr::ceil_div(C, 64)), dim3(64), 0,
+                     (hipStream_t)stream, C, in, out, in_translation);
+  GSR_CHECK_LAUNCH("inverse4x4");
+  return GSR_OK;
+}
 
 // params/grads/exp_avg/exp_avg_sq: HOST arrays of n device pointers (16-byte
 // aligned tensors); numel, step_size (= lr/(1-beta1^t)), bc2_sqrt

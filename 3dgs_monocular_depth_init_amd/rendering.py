@@ -27,6 +27,7 @@ from ._lib import call, ptr
 
 TILE = 16
 GRAD_ROW = 16
+ACT_EXP_SCALES, ACT_SIGMOID_OPAC = 1, 2      # GSR_ACT_* of include/gsrast.h
 GR_MEAN2D, GR_CONIC, GR_OPAC, GR_COLOR, GR_ABS = 0, 2, 5, 6, 12
 
 
@@ -62,9 +63,13 @@ class _ProjectSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg):
         (width, height, eps2d, near, far, radius_clip, calc_comp, sh_degree, color_stride,
-         depth_channel) = cfg
+         depth_channel, activations, tile_w, tile_h) = cfg
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
+        opac_act = (torch.empty(N, dtype=torch.float32, device=dev)
+                    if activations & ACT_SIGMOID_OPAC else None)
+        tile_counts = (torch.empty(C * tile_w * tile_h, dtype=torch.int32, device=dev)
+                       if tile_w > 0 else None)
         radii = torch.empty(C, N, 2, dtype=torch.int32, device=dev)
         means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         depths = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -89,27 +94,41 @@ class _ProjectSH(torch.autograd.Function):
              ptr(viewmats), ptr(Ks), ptr(campos), width, height, eps2d, near, far, radius_clip,
              int(calc_comp), sh_degree, sh0_ptr, sh0_stride, shN_ptr, shN_stride, ptr(radii),
              ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(colors), color_stride,
-             depth_channel, _stream())
+             depth_channel, activations, ptr(opac_act), tile_w, tile_h, ptr(tile_counts),
+             _stream())
         ctx.cfg = cfg
         ctx.split = sh_b is not None
-        ctx.save_for_backward(means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii)
-        ctx.mark_non_differentiable(radii)
-        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii,
+                              opac_act)
         if comps is None:
             comps = torch.empty(0, device=dev)
         if colors is None:
             colors = torch.empty(0, device=dev)
-        return radii, means2d, depths, conics, comps, colors
+        if opac_act is None:
+            opac_act = torch.empty(0, device=dev)
+        if tile_counts is None:
+            tile_counts = torch.empty(0, dtype=torch.int32, device=dev)
+        ctx.mark_non_differentiable(radii, tile_counts)
+        ctx.set_materialize_grads(False)
+        return radii, means2d, depths, conics, comps, colors, opac_act, tile_counts
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_colors):
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_colors, v_opac_act,
+                 _v_tc):
         (width, height, eps2d, near, far, radius_clip, calc_comp, sh_degree, color_stride,
-         depth_channel) = ctx.cfg
-        means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii = ctx.saved_tensors
+         depth_channel, activations, tile_w, tile_h) = ctx.cfg
+        (means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii,
+         opac_act) = ctx.saved_tensors
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
-        rows = _rows_from_grads(C, N, v_means2d, v_conics, v_colors if sh_degree >= 0 else None,
-                                color_stride)
+        rows, fast = _rows_from_grads(C, N, v_means2d, v_conics,
+                                      v_colors if sh_degree >= 0 else None, color_stride)
+        v_opacities = None
+        if activations & ACT_SIGMOID_OPAC:
+            # the kernel sums rows[.][GR_OPAC] over cameras and applies o(1-o)
+            if not fast and v_opac_act is not None:
+                rows.view(C, N, GRAD_ROW)[0, :, GR_OPAC] = v_opac_act.reshape(N)
+            v_opacities = torch.empty(N, dtype=torch.float32, device=dev)
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
         v_scales = torch.empty_like(scales)
@@ -142,8 +161,9 @@ class _ProjectSH(torch.autograd.Function):
              ptr(campos), width, height, eps2d, sh_degree, sh0_ptr, sh0_stride, shN_ptr,
              shN_stride, ptr(radii), None, None, ptr(rows), ptr(v_depths), ptr(v_comps),
              depth_channel if sh_degree >= 0 else -1, ptr(v_means), ptr(v_quats), ptr(v_scales),
-             v_sh0_ptr, v0_stride, v_shN_ptr, vN_stride, K, _stream())
-        return v_means, v_quats, v_scales, None, v_sh_a, v_sh_b, None, None, None, None
+             v_sh0_ptr, v0_stride, v_shN_ptr, vN_stride, K, activations, ptr(opac_act),
+             ptr(v_opacities), _stream())
+        return v_means, v_quats, v_scales, v_opacities, v_sh_a, v_sh_b, None, None, None, None
 
 
 def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride: int) -> Tensor:
@@ -170,7 +190,7 @@ def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride
         base = b
     else:
         if base is not None:
-            return base
+            return base, True
     any_v = next((v for v in (v_means2d, v_conics, v_colors) if v is not None), None)
     dev = any_v.device if any_v is not None else torch.device("cuda")
     rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
@@ -181,7 +201,18 @@ def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride
     if v_colors is not None:
         w = v_colors.shape[-1]
         rows[:, GR_COLOR:GR_COLOR + w] = v_colors.reshape(C * N, w)
-    return rows
+    return rows, False
+
+
+@torch.no_grad()
+def inverse4x4(mats: Tensor) -> Tuple[Tensor, Tensor]:
+    """Batched 4x4 inverse on the device in one launch. Returns (inverse [C,4,4],
+    translation column of the INVERSE [C,3])."""
+    mats = _f32c(mats)
+    C = mats.shape[0]
+    out = torch.empty_like(mats)
+    call("gsr_inverse4x4", C, ptr(mats), ptr(out), None, _stream())
+    return out, out[:, :3, 3].contiguous()
 
 
 # --------------------------------------------------------------------------- #
@@ -189,20 +220,23 @@ def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride
 # --------------------------------------------------------------------------- #
 @torch.no_grad()
 def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
-                       want_tiles_per_gauss: bool = False):
+                       want_tiles_per_gauss: bool = False, tile_counts: Optional[Tensor] = None):
     """Returns (tile_offsets [n_tiles+1] int32, tile_order [n_tiles] int32 (longest list
     first), flatten_ids [I] int32, isect_keys [I] int64 (depth_bits<<32 | g, sorted per
     tile), tiles_per_gauss or None)."""
     C, N = depths.shape
     dev = depths.device
     n_tiles = C * tile_w * tile_h
-    tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    counted = tile_counts is not None and tile_counts.numel() == n_tiles and not want_tiles_per_gauss
+    if not counted:
+        tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     tpg = torch.empty(C, N, dtype=torch.int32, device=dev) if want_tiles_per_gauss else None
     st = _stream()
-    call("gsr_isect_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(tpg),
-         ptr(tile_counts), st)
+    if not counted:      # otherwise the projection kernel already counted (fused A5 pass 1)
+        call("gsr_isect_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(tpg),
+             ptr(tile_counts), st)
     call("gsr_isect_scan", n_tiles, ptr(tile_counts), ptr(tile_offsets), ptr(tile_order), st)
     n_isects = int(tile_offsets[-1].item())          # the one host sync of the step
     keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
@@ -306,12 +340,20 @@ def rasterization(
     distributed: bool = False,
     camera_model: str = "pinhole",
     covars: Optional[Tensor] = None,
+    _raw_activations: bool = False,
+    _campos: Optional[Tensor] = None,
     **unsupported,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
     memory layout, never the rendered result: both values run the same dense
     [C,N] kernels here (and `meta` keeps the dense layout), `sparse_grad`
-    (needs packed indices) is rejected."""
+    (needs packed indices) is rejected.
+
+    Private extensions used by `runner.rasterize_splats` (not part of gsplat's
+    signature): `_raw_activations=True` means `scales` are log-scales and
+    `opacities` logits, i.e. the exp/sigmoid of runner.py:324-325 (and their
+    backward) run inside the projection kernels; `_campos` [C,3] supplies the
+    camera centres so that the view matrices need not be inverted again."""
     if unsupported:
         raise TypeError(f"rasterization(): unsupported arguments {sorted(unsupported)}")
     if camera_model != "pinhole":
@@ -358,17 +400,28 @@ def rasterization(
             sh_a = _f32c(colors)
         color_stride = 4 if with_depth else 3
         depth_channel = 3 if with_depth else -1
-        campos = torch.linalg.inv(viewmats)[:, :3, 3].contiguous()
+        campos = _f32c(_campos) if _campos is not None else inverse4x4(viewmats)[1]
     else:
         color_stride, depth_channel, campos = 0, -1, None
 
+    tile_w = math.ceil(width / TILE)
+    tile_h = math.ceil(height / TILE)
+    activations = 0
+    if _raw_activations:
+        # the sigmoid chain rule is fused only when the compositing gradient of the
+        # opacity reaches the projection backward unchanged (classic mode)
+        activations = ACT_EXP_SCALES | (0 if antialiased else ACT_SIGMOID_OPAC)
+        if antialiased:
+            opacities = torch.sigmoid(opacities)
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
            float(radius_clip), bool(antialiased), int(sh_degree) if use_sh else -1, color_stride,
-           depth_channel)
-    radii, means2d, depths, conics, comps, sh_colors = _ProjectSH.apply(
+           depth_channel, activations, tile_w, tile_h)
+    radii, means2d, depths, conics, comps, sh_colors, opac_act, tile_counts = _ProjectSH.apply(
         means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg)
 
-    if antialiased:
+    if activations & ACT_SIGMOID_OPAC:
+        opac = opac_act                                # [N], sigmoid done in the kernel
+    elif antialiased:
         opac = opacities[None, :] * comps              # [C,N]
     else:
         opac = opacities
@@ -398,10 +451,9 @@ def rasterization(
             backgrounds = torch.zeros(C, 1, dtype=torch.float32, device=means.device)
         backgrounds = backgrounds.contiguous()
 
-    tile_w = math.ceil(width / TILE)
-    tile_h = math.ceil(height / TILE)
     tile_offsets, tile_order, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
-        means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False)
+        means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False,
+        tile_counts=tile_counts)
 
     rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
     render_colors, render_alphas, _last = _Rasterize.apply(

@@ -18,7 +18,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from .rendering import rasterization
+from .rendering import inverse4x4, rasterization
 
 SH_C0 = 0.28209479177387814          # utils/runner_utils.py:150
 
@@ -115,17 +115,19 @@ def rasterize_splats(
     runner.py:338 (192 B/Gaussian read + write) is not materialised."""
     means = splats["means"]
     quats = splats["quats"]                         # normalised inside the kernel
-    scales = torch.exp(splats["scales"])
-    opacities = torch.sigmoid(splats["opacities"])
     kwargs.pop("image_ids", None)
     colors = (splats["sh0"], splats["shN"])
     rasterize_mode = "antialiased" if cfg.antialiased else "classic"
+    # runner.py:324-325 (exp / sigmoid) run inside the projection kernels, and
+    # runner.py:347 `torch.linalg.inv(camtoworlds)` is one small launch
+    viewmats, _ = inverse4x4(camtoworlds)
+    campos = camtoworlds[:, :3, 3].float().contiguous()
     render_colors, render_alphas, info = rasterization(
-        means=means, quats=quats, scales=scales, opacities=opacities, colors=colors,
-        viewmats=torch.linalg.inv(camtoworlds), Ks=Ks, width=width, height=height,
+        means=means, quats=quats, scales=splats["scales"], opacities=splats["opacities"],
+        colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
         packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=False,
         rasterize_mode=rasterize_mode, distributed=False, camera_model=cfg.camera_model,
-        **kwargs,
+        _raw_activations=True, _campos=campos, **kwargs,
     )
     if masks is not None:
         render_colors[~masks] = 0

@@ -49,6 +49,10 @@ extern "C" {
 #define GSR_GR_OPAC 5     /* 1: dL/d opacity                 */
 #define GSR_GR_COLOR 6    /* CH (<=5): dL/d colour channels  */
 #define GSR_GR_ABS 12     /* 2: sum |dL/d means2d| (absgrad) */
+/* `activations` bits of gsr_project_fwd/bwd: the reference's A1 step
+ * (gs_init_compare/runner.py:324-325) fused into the kernels. */
+#define GSR_ACT_EXP_SCALES 1   /* `scales` holds log-scales: scale = exp(raw)          */
+#define GSR_ACT_SIGMOID_OPAC 2 /* `opacities` holds logits: opacity = sigmoid(raw)     */
 
 int gsr_version(void);
 const char *gsr_last_error(void);
@@ -74,7 +78,11 @@ int gsr_project_fwd(int C, int N, const float *means, const float *quats, const 
                     int32_t *radii /* [C,N,2] */, float *means2d /* [C,N,2] */,
                     float *depths /* [C,N] */, float *conics /* [C,N,3] */,
                     float *compensations /* [C,N] or NULL */, float *colors_out /* or NULL */,
-                    int color_stride, int depth_channel, void *stream);
+                    int color_stride, int depth_channel, int activations /* GSR_ACT_* */,
+                    float *opacities_out /* [N] activated opacities (with GSR_ACT_SIGMOID_OPAC) */,
+                    int tile_w, int tile_h,
+                    int32_t *tile_counts /* NULL, or [C*tile_h*tile_w]: fused gsr_isect_count */,
+                    void *stream);
 
 /* Backward of gsr_project_fwd. grad_rows is the [C*N, GSR_GRAD_ROW] scratch
  * filled by gsr_rasterize_bwd (fields GSR_GR_*). v_depths [C,N] may be NULL
@@ -89,7 +97,11 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
                     const float *v_compensations, int depth_channel, float *v_means /* [N,3] */,
                     float *v_quats /* [N,4] */, float *v_scales /* [N,3] */,
                     float *v_sh0 /* or NULL */, int v_sh0_stride, float *v_shN, int v_shN_stride,
-                    int sh_K /* coefficients stored per Gaussian */, void *stream);
+                    int sh_K /* coefficients stored per Gaussian */, int activations,
+                    const float *opacities_act /* [N], needed with GSR_ACT_SIGMOID_OPAC */,
+                    float *v_opacities /* NULL, or [N]: sum over cameras of grad_rows[.][GSR_GR_OPAC]
+                                          (times o(1-o) with GSR_ACT_SIGMOID_OPAC) */,
+                    void *stream);
 
 /* ---------------------------------------------------------------------------
  * A5: per-tile depth-sorted intersection lists.
@@ -155,6 +167,12 @@ int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *c
 int gsr_adam_step(int n, void *const *params, const void *const *grads, void *const *exp_avg,
                   void *const *exp_avg_sq, const int64_t *numel, const float *step_size,
                   const float *bc2_sqrt, double beta1, double beta2, double eps, void *stream);
+
+/* Batched inverse of C row-major 4x4 matrices (viewmats = inv(camtoworlds),
+ * gs_init_compare/runner.py:347). in_translation [C,3] (optional) receives the
+ * translation column of the INPUT (the camera position when `in` is
+ * camera-to-world). */
+int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.

@@ -194,3 +194,44 @@ def test_long_tile_lists(R):
                                    torch.tensor([flat.numel()], dtype=torch.int32)]))
     assert counts.max().item() > 8192
     _check(cpu, gpu, out_c, out_g)
+
+
+@pytest.mark.parametrize("antialiased", [False, True])
+@pytest.mark.parametrize("cams", [[0], [0, 40]])
+def test_runner_rasterize_splats_fused_activations(R, antialiased, cams):
+    """runner.rasterize_splats (A1): exp / sigmoid and their backward run inside the
+    projection kernels; gradients w.r.t. the RAW parameters must match autograd
+    through torch.exp / torch.sigmoid + the oracle."""
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    sc = scenes.make_scene(700, 4, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras(cams, width=W, height=H, f=90.0, dist=2.5)
+    raw = dict(means=sc["means"], quats=sc["quats"], scales=torch.log(sc["scales"]),
+               opacities=torch.logit(sc["opacities"]), sh0=sc["sh0"], shN=sc["shN"])
+    cpu = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    gpu = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().cuda()) for k, v in raw.items()})
+    mode = "antialiased" if antialiased else "classic"
+    rc_c, ra_c, _ = O.rasterization(
+        cpu["means"], cpu["quats"], torch.exp(cpu["scales"]), torch.sigmoid(cpu["opacities"]),
+        torch.cat([cpu["sh0"], cpu["shN"]], 1), vm, K, W, H, sh_degree=3, rasterize_mode=mode)
+    cfg = runner.RasterConfig(antialiased=antialiased)
+    rc_g, ra_g, info = runner.rasterize_splats(gpu, torch.linalg.inv(vm).cuda(), K.cuda(), W, H, cfg,
+                                               sh_degree=3)
+    g = torch.Generator().manual_seed(3)
+    w_c, w_a = torch.randn(rc_c.shape, generator=g), torch.randn(ra_c.shape, generator=g)
+    ((rc_c * w_c).sum() + (ra_c * w_a).sum()).backward()
+    ((rc_g * w_c.cuda()).sum() + (ra_g * w_a.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    assert (rc_g.detach().cpu() - rc_c.detach()).abs().max() <= 5e-4
+    for k in raw:
+        got, ref = gpu[k].grad.cpu(), cpu[k].grad
+        l2 = float((got - ref).norm() / ref.norm().clamp_min(1e-20))
+        assert l2 <= GRAD_RTOL, f"grad {k}: L2 rel err {l2:.3e}"
+
+
+def test_inverse4x4_matches_torch(R):
+    vm, _ = scenes.cameras([0, 13, 77])
+    inv, campos = R.inverse4x4(vm.cuda())
+    ref = torch.linalg.inv(vm)
+    assert torch.allclose(inv.cpu(), ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(campos.cpu(), ref[:, :3, 3], rtol=1e-5, atol=1e-6)
