@@ -68,6 +68,45 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float,
                             __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// ---- 8 values x 64 lanes -> 8 totals in 18 VALU ops (instead of 8 x 6) ------
+// Halving tree on the gfx950 lane-swap instructions: each level folds the wave
+// in half AND packs two values into one register, so the work shrinks
+// 8 -> 4 -> 2 -> 1 registers. On return, every lane of (row r = lane/16,
+// half h = (lane/8)&1) holds the 64-lane total of v[TREE8_INDEX[h][r]].
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  // lanes 0-31: a folded over the two 32-lane halves; lanes 32-63: b folded
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  // NB: copy the elements out first -- `__builtin_bit_cast(float, r[1])` applied to
+  // the vector element directly is miscompiled by ROCm 7.2 clang (reads r[0] twice).
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float swap16_add(float p, float q) {
+  // rows: [p0+p1, q0+q1, p2+p3, q2+q3]
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return __uint_as_float(r0) + __uint_as_float(r1);
+}
+__device__ __forceinline__ float tree_reduce8(const float v[8], int lane) {
+  const float s01 = swap32_add(v[0], v[1]), s23 = swap32_add(v[2], v[3]);
+  const float s45 = swap32_add(v[4], v[5]), s67 = swap32_add(v[6], v[7]);
+  const float r1 = swap16_add(s01, s23);     // rows: v0, v2, v1, v3 (16 partial lanes each)
+  const float r2 = swap16_add(s45, s67);     // rows: v4, v6, v5, v7
+  const float t1 = dpp_add<0x128>(r1);       // row_ror:8 -> fold the two 8-lane halves
+  const float t2 = dpp_add<0x128>(r2);
+  float u = (lane & 8) ? t2 : t1;
+  u = dpp_add<0xb1>(u);                      // quad_perm [1,0,3,2]
+  u = dpp_add<0x4e>(u);                      // quad_perm [2,3,0,1]
+  u = dpp_add<0x141>(u);                     // row_half_mirror: the other quad of the half
+  return u;
+}
+// value index held by (half h, row r) after tree_reduce8
+__device__ __forceinline__ int tree8_index(int lane) {
+  const int r = lane >> 4, h = (lane >> 3) & 1;
+  const int base = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3;
+  return base + 4 * h;
+}
+
 // Tile rectangle [x0,x1) x [y0,y1) a projected Gaussian touches (A.3): mean +- radius in
 // tile units, clamped to the grid. false = culled / touches nothing.
 __device__ __forceinline__ bool tile_rect_v(float mean_x, float mean_y, int rx, int ry, int tile_w,

@@ -51,6 +51,15 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
 
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e <= s) return;
+  // which field of a gradient row this lane stores after tree_reduce8 (-1: none).
+  // tree values: 0,1 = first moments (slots MEAN2D), 2..4 = conic, 5..7 = colours 0..2
+  int tree_field = -1;
+  if ((lane & 7) == 0) {
+    const int ti = tree8_index(lane);
+    tree_field = (ti < 2) ? GSR_GR_MEAN2D + ti
+                 : (ti < 5) ? GSR_GR_CONIC + (ti - 2)
+                 : ((ti - 5) < CH ? GSR_GR_COLOR + (ti - 5) : -1);
+  }
 
   // Kq = T_final * (v_alpha_out - <background, v_out>): the per-pixel constant of v_alpha
   float px[4], py[2], T[4], Kq[4], buf_c[4][CH], vout[4][CH];
@@ -179,38 +188,36 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
         }
       }
       if (!__any(any_valid)) continue;  // wave-uniform skip
-      // row reduction on DPP, then 4 lanes (one per row) add into the LDS row
-      const float m_x = row_sum16(g_xy[0]), m_y = row_sum16(g_xy[1]);
-      const float r_x = fmaf(ca, m_x, cb * m_y), r_y = fmaf(cb, m_x, cc * m_y);
-      const float r_a = row_sum16(g_con[0]), r_b = row_sum16(g_con[1]), r_c = row_sum16(g_con[2]);
-      const float r_o = row_sum16(g_op);
-      float r_col[CH];
-#pragma unroll
-      for (int k = 0; k < CH; ++k) r_col[k] = row_sum16(g_col[k]);
-      float r_ax = 0.f, r_ay = 0.f;
-      if (ABSGRAD) {
-        r_ax = row_sum16(g_abs[0]);
-        r_ay = row_sum16(g_abs[1]);
+      // 8 of the sums go through the lane-swap halving tree (18 VALU for all 8),
+      // the rest through plain wave sums; writer lanes store straight into the
+      // batch's 64-byte LDS row.
+      {
+        const float tv[8] = {g_xy[0], g_xy[1], g_con[0], g_con[1], g_con[2], g_col[0],
+                             (CH > 1) ? g_col[1] : 0.f, (CH > 2) ? g_col[2] : 0.f};
+        const float u = tree_reduce8(tv, lane);
+        const float r_o = wave_sum(g_op);
+        float *row = &sG[j][0];
+        if (tree_field >= 0) row[tree_field] = u;      // 8 writer lanes
+        if (lane == 0) {
+          row[GSR_GR_OPAC] = r_o;
+          row[15] = 1.0f;                              // "row touched" flag
+        }
+        if (CH > 3) {
+          const float r3 = wave_sum(g_col[3]);
+          if (lane == 0) row[GSR_GR_COLOR + 3] = r3;
+        }
+        if (CH > 4) {
+          const float r4 = wave_sum(g_col[4]);
+          if (lane == 0) row[GSR_GR_COLOR + 4] = r4;
+        }
+        if (ABSGRAD) {
+          const float r_ax = wave_sum(g_abs[0]), r_ay = wave_sum(g_abs[1]);
+          if (lane == 0) {
+            row[GSR_GR_ABS] = r_ax;
+            row[GSR_GR_ABS + 1] = r_ay;
+          }
+        }
       }
-      // lane (16*row + f) picks field f of its row's sums, the four rows are
-      // folded with two cross-row shuffles, lanes 0..15 store the 64-byte row.
-      const int f16 = lane & 15;
-      float val = (f16 == 15) ? 1.0f : 0.f;          // field 15 = "row touched" flag
-      val = (f16 == GSR_GR_MEAN2D) ? r_x : val;
-      val = (f16 == GSR_GR_MEAN2D + 1) ? r_y : val;
-      val = (f16 == GSR_GR_CONIC) ? r_a : val;
-      val = (f16 == GSR_GR_CONIC + 1) ? r_b : val;
-      val = (f16 == GSR_GR_CONIC + 2) ? r_c : val;
-      val = (f16 == GSR_GR_OPAC) ? r_o : val;
-#pragma unroll
-      for (int k = 0; k < CH; ++k) val = (f16 == GSR_GR_COLOR + k) ? r_col[k] : val;
-      if (ABSGRAD) {
-        val = (f16 == GSR_GR_ABS) ? r_ax : val;
-        val = (f16 == GSR_GR_ABS + 1) ? r_ay : val;
-      }
-      val += __shfl_xor(val, 16, 64);
-      val += __shfl_xor(val, 32, 64);
-      if (lane < GSR_GRAD_ROW) sG[j][lane] = val;
     }
     __syncthreads();
     // flush: 4 Gaussians per wave instruction, 16 lanes = one 64-byte row
@@ -221,12 +228,34 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
       const int j = j0 + (lane >> 4);
       if (j < n && field_used && sG[j][15] != 0.f) {
         const int g = sId[buf][j];
-        atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, sG[j][f]);
+        float val = sG[j][f];
+        if (f < 2) {   // v_xy = conic * (first moments): row holds (m_x, m_y)
+          const float4 Aj = sA[buf][j];
+          const float4 Bj = sB[buf][j];
+          const float ca = Aj.z * (2.0f / LOG2E), cb = Aj.w * (1.0f / LOG2E),
+                      cc = Bj.x * (2.0f / LOG2E);
+          const float mx_ = sG[j][0], my_ = sG[j][1];
+          val = (f == 0) ? fmaf(ca, mx_, cb * my_) : fmaf(cb, mx_, cc * my_);
+        }
+        atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, val);
       }
     }
     __syncthreads();
     buf ^= 1;
   }
+}
+
+// Test hook for the lane-swap tree (the semantics of v_permlane{16,32}_swap are
+// checked on the GPU by tests/test_gpu_rasterization.py::test_tree_reduce8).
+__global__ void debug_tree_reduce8_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                          int *__restrict__ idx_out) {
+  const int lane = threadIdx.x;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = in[k * 64 + lane];
+  out[lane] = tree_reduce8(v, lane);
+  idx_out[lane] = tree8_index(lane);
+  out[64 + lane] = wave_sum(v[0]);
 }
 
 template <int CH>
@@ -255,6 +284,15 @@ static int launch_bwd(int n_tiles, int N, const float *means2d, const float *con
 }
 
 }  // namespace gsr
+
+extern "C" int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_out,
+                                      void *stream) {
+  GSR_REQUIRE(in && out && idx_out, "debug_tree_reduce8: null pointer");
+  hipLaunchKernelGGL(gsr::debug_tree_reduce8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     in, out, idx_out);
+  GSR_CHECK_LAUNCH("debug_tree_reduce8");
+  return GSR_OK;
+}
 
 extern "C" int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *conics,
                                  const float *colors, int color_stride, const float *opacities,

@@ -168,6 +168,11 @@ int gsr_adam_step(int n, void *const *params, const void *const *grads, void *co
                   void *const *exp_avg_sq, const int64_t *numel, const float *step_size,
                   const float *bc2_sqrt, double beta1, double beta2, double eps, void *stream);
 
+/* Test hook: in [8][64] -> out[0..63] = per-lane result of the 8-value lane-swap
+ * reduction tree used by gsr_rasterize_bwd, out[64..127] = wave sum of in[0],
+ * idx_out[64] = which input each lane holds the total of. */
+int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_out, void *stream);
+
 /* Batched inverse of C row-major 4x4 matrices (viewmats = inv(camtoworlds),
  * gs_init_compare/runner.py:347). in_translation [C,3] (optional) receives the
  * translation column of the INPUT (the camera position when `in` is

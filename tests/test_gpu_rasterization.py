@@ -235,3 +235,22 @@ def test_inverse4x4_matches_torch(R):
     ref = torch.linalg.inv(vm)
     assert torch.allclose(inv.cpu(), ref, rtol=1e-5, atol=1e-6)
     assert torch.allclose(campos.cpu(), ref[:, :3, 3], rtol=1e-5, atol=1e-6)
+
+
+def test_tree_reduce8(R):
+    """Lane semantics of the v_permlane32_swap / v_permlane16_swap / DPP halving
+    tree the compositing backward reduces with."""
+    lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 64, generator=g, dtype=torch.float32)
+    xin = x.cuda().contiguous()
+    out = torch.empty(128, device="cuda")
+    idx = torch.empty(64, dtype=torch.int32, device="cuda")
+    lib.call("gsr_debug_tree_reduce8", xin.data_ptr(), out.data_ptr(), idx.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    tot = x.double().sum(1)
+    idx = idx.cpu().long()
+    assert sorted(set(idx.tolist())) == list(range(8))
+    assert torch.allclose(out[:64].cpu().double(), tot[idx], atol=1e-4)
+    assert torch.allclose(out[64:].cpu().double(), tot[0].expand(64), atol=1e-4)
