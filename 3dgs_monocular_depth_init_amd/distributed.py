@@ -22,40 +22,67 @@ PARAM_ORDER = ("shN", "sh0", "means", "quats", "scales", "opacities")
 
 
 class GradSync:
-    """All-reduce the gradients of the six parameter tensors.
+    """All-reduce (sum) the gradients of the six parameter tensors.
 
-    Gradients are summed (the loss of a W-view batch is the sum of the
-    per-view losses, as with the reference's batch dimension) unless
-    `average=True`. Buckets follow PARAM_ORDER: SH gradients (180 B of the
-    236 B per Gaussian) are final first in the backward pass, means last, so
-    the large message overlaps the tail of backward when hooks are used.
-    """
+    Fast path: a `rendering.GradArena` is registered, so after backward every
+    `p.grad` is a view of one flat buffer and ONE collective moves all 59*N
+    floats (a single large message is what RCCL's xGMI paths are best at).
+    Fallback (grads that are not arena views, e.g. CPU/gloo tests, extra
+    autograd consumers): one async all-reduce per tensor, SH first.
+    Gradients are summed (the loss of a W-view batch is the sum of per-view
+    losses, as with the reference's batch dimension) unless `average=True`."""
 
-    def __init__(self, splats, world_size: int, average: bool = False, group=None):
+    def __init__(self, splats, world_size: int, average: bool = False, group=None,
+                 use_arena: bool = True):
         self.splats = splats
         self.world = world_size
         self.average = average
         self.group = group
+        self.arena = None
+        self.use_arena = use_arena
+        self._maybe_build_arena()
+
+    def _maybe_build_arena(self) -> None:
+        if not self.use_arena:
+            return
+        first = next(iter(self.splats.values()))
+        if not first.is_cuda:
+            return
+        shapes = {k: tuple(p.shape) for k, p in self.splats.items()}
+        if self.arena is None or self.arena.shapes != shapes:     # also after densification
+            from .rendering import GradArena, set_grad_arena
+            self.arena = GradArena(shapes, first.device)
+            set_grad_arena(self.arena)
 
     def __call__(self) -> None:
+        if self.arena is not None:
+            self.arena.reset()
         if self.world <= 1:
+            self._maybe_build_arena()
             return
-        works = []
-        for name in PARAM_ORDER:
-            if name not in self.splats:
-                continue
-            g = self.splats[name].grad
-            if g is None:
-                g = torch.zeros_like(self.splats[name])
-                self.splats[name].grad = g
-            if not g.is_contiguous():
-                g = g.contiguous()
-                self.splats[name].grad = g
-            works.append((g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
-        for g, w in works:
-            w.wait()
+        names = [n for n in PARAM_ORDER if n in self.splats]
+        if self.arena is not None and all(self.arena.owns(n, self.splats[n].grad) for n in names) \
+                and len(names) == len(self.arena.offsets):
+            dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.average:
-                g.div_(self.world)
+                self.arena.flat.div_(self.world)
+        else:
+            works = []
+            for name in names:
+                g = self.splats[name].grad
+                if g is None:
+                    g = torch.zeros_like(self.splats[name])
+                    self.splats[name].grad = g
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    self.splats[name].grad = g
+                works.append((g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True)))
+            for g, w in works:
+                w.wait()
+                if self.average:
+                    g.div_(self.world)
+        self._maybe_build_arena()
 
 
 def shard_views(n_views: int, step: int, rank: int, world: int, perm=None) -> int:

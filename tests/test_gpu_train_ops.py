@@ -71,3 +71,44 @@ def test_values_loop_compat():
         assert ps[k].grad is None
         assert (ps[k].detach() != before[k]).all()
         assert float(opts[k].state[ps[k]]["step"]) == 1
+
+
+def test_grad_arena_hands_out_views_and_matches_plain_grads():
+    """distributed.GradSync registers a flat gradient arena: after backward every
+    p.grad is a view of ONE buffer (a single all-reduce message) with the same
+    values as the separately allocated gradients."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 3001                                     # odd sizes exercise the 16-byte padding
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, device="cuda")
+
+    def make():
+        return runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)),
+            torch.log(sc["scales"]), quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]),
+            shN=sc["shN"])[0]
+
+    plain = make()
+    runner.train_step(plain, None, c2w, K, target, step=5000)
+    ref = {k: p.grad.clone() for k, p in plain.items()}
+    try:
+        splats = make()
+        sync = D.GradSync(splats, 1)
+        assert sync.arena is not None and sync.arena.flat.numel() >= 59 * N
+        runner.train_step(splats, None, c2w, K, target, step=5000, grad_sync=sync)
+        for k, p in splats.items():
+            assert sync.arena.owns(k, p.grad), k
+            assert torch.allclose(p.grad, ref[k], rtol=1e-4, atol=1e-7 + 1e-5 * float(ref[k].abs().max())), k
+        # second step reuses the same memory
+        for p in splats.values():
+            p.grad = None
+        runner.train_step(splats, None, c2w, K, target, step=5000, grad_sync=sync)
+        assert all(sync.arena.owns(k, p.grad) for k, p in splats.items())
+    finally:
+        R.set_grad_arena(None)
