@@ -34,6 +34,8 @@ SIGNATURES = {
     "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
                           _p, _p, _p, _i, _p, _p],
 }
+SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]
+SIGNATURES["gsr_ssim_l1_bwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_debug_tree_reduce8"] = [_p, _p, _p, _p]
 SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p]
 SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]

@@ -1,0 +1,244 @@
+// ssim.hip -- F1: fused L1 + SSIM training loss (forward and backward).
+//
+// Replaces, in the step body of gs_init_compare/runner.py:506-510,
+//   l1loss   = F.l1_loss(colors, pixels)
+//   ssimloss = 1 - fused_ssim(colors.permute(0,3,1,2), pixels.permute(0,3,1,2), padding="valid")
+//   loss     = l1loss * (1 - ssim_lambda) + ssimloss * ssim_lambda
+// (`fused_ssim` = rahul-goel/fused-ssim @30fb258, a third-party CUDA op pinned at
+// setup.py:14: 11x11 Gaussian window, sigma 1.5, C1 = 0.01^2, C2 = 0.03^2, zero
+// padding for the window, "valid" = mean over the map cropped by 5 pixels).
+//
+// HBM-bound: two passes over two images. Each workgroup owns a 32x32 output
+// tile of one (image, channel) plane; the 42x42 input halo tile is staged in
+// LDS and the 11-tap window is applied separably (rows, then columns) from LDS.
+// Images are addressed with element strides, so the rasterizer's NHWC output is
+// consumed in place (no permute().contiguous() copies).
+#include "common.h"
+
+namespace gsr {
+
+constexpr int SSIM_R = 5;                 // window radius (11 taps)
+constexpr int SSIM_T = 32;                // output tile edge
+constexpr int SSIM_H = SSIM_T + 2 * SSIM_R;   // halo tile edge (42)
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+
+// exp(-(i-5)^2 / (2*1.5^2)) normalised to sum 1
+__constant__ float SSIM_G[11] = {0.001028380123898387f, 0.0075987582094967365f,
+                                 0.036000773310661316f, 0.10936068743467331f,
+                                 0.21300552785396576f,  0.26601171493530273f,
+                                 0.21300552785396576f,  0.10936068743467331f,
+                                 0.036000773310661316f, 0.0075987582094967365f,
+                                 0.001028380123898387f};
+
+struct ImgView {          // element strides of an [N, CH, H, W] logical image
+  int64_t sn, sc, sh, sw;
+};
+
+__device__ __forceinline__ float ld(const float *p, const ImgView &v, int n, int c, int y, int x,
+                                    int H, int W) {
+  if (x < 0 || y < 0 || x >= W || y >= H) return 0.f;
+  return p[n * v.sn + c * v.sc + y * v.sh + x * v.sw];
+}
+
+// Forward: per-pixel SSIM (+ L1) summed into sums[0] (ssim over the counted
+// region) and sums[1] (sum |x-y| over all pixels); optionally the three
+// derivative maps for the backward.
+__global__ void __launch_bounds__(256)
+ssim_fwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
+                const float *__restrict__ img2, ImgView v2, int valid_only,
+                double *__restrict__ sums, float *__restrict__ dm_mu1,
+                float *__restrict__ dm_s1, float *__restrict__ dm_s12) {
+  __shared__ float sX[SSIM_H][SSIM_H + 1];
+  __shared__ float sY[SSIM_H][SSIM_H + 1];
+  __shared__ float sHz[5][SSIM_H][SSIM_T + 1];   // row-filtered: x, y, xx, yy, xy
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + SSIM_T - 1) / SSIM_T;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
+  const int x0 = bx * SSIM_T - SSIM_R, y0 = by * SSIM_T - SSIM_R;
+
+  for (int i = tid; i < SSIM_H * SSIM_H; i += 256) {
+    const int ly = i / SSIM_H, lx = i % SSIM_H;
+    sX[ly][lx] = ld(img1, v1, n, c, y0 + ly, x0 + lx, H, W);
+    sY[ly][lx] = ld(img2, v2, n, c, y0 + ly, x0 + lx, H, W);
+  }
+  __syncthreads();
+  for (int i = tid; i < SSIM_H * SSIM_T; i += 256) {
+    const int ly = i / SSIM_T, lx = i % SSIM_T;
+    float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = SSIM_G[k], x = sX[ly][lx + k], y = sY[ly][lx + k];
+      a = fmaf(g, x, a);
+      b = fmaf(g, y, b);
+      aa = fmaf(g, x * x, aa);
+      bb = fmaf(g, y * y, bb);
+      ab = fmaf(g, x * y, ab);
+    }
+    sHz[0][ly][lx] = a;
+    sHz[1][ly][lx] = b;
+    sHz[2][ly][lx] = aa;
+    sHz[3][ly][lx] = bb;
+    sHz[4][ly][lx] = ab;
+  }
+  __syncthreads();
+  double acc_ssim = 0.0, acc_l1 = 0.0;
+  for (int i = tid; i < SSIM_T * SSIM_T; i += 256) {
+    const int ly = i / SSIM_T, lx = i % SSIM_T;
+    const int gx = bx * SSIM_T + lx, gy = by * SSIM_T + ly;
+    if (gx >= W || gy >= H) continue;
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = SSIM_G[k];
+      mu1 = fmaf(g, sHz[0][ly + k][lx], mu1);
+      mu2 = fmaf(g, sHz[1][ly + k][lx], mu2);
+      e11 = fmaf(g, sHz[2][ly + k][lx], e11);
+      e22 = fmaf(g, sHz[3][ly + k][lx], e22);
+      e12 = fmaf(g, sHz[4][ly + k][lx], e12);
+    }
+    const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+    const float A = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B = s1 + s2 + SSIM_C2;
+    const float Cc = 2.f * mu1 * mu2 + SSIM_C1, D = 2.f * s12 + SSIM_C2;
+    const float iAB = 1.0f / (A * B);
+    const float m = Cc * D * iAB;
+    const bool counted = !valid_only || (gx >= SSIM_R && gx < W - SSIM_R && gy >= SSIM_R && gy < H - SSIM_R);
+    if (counted) acc_ssim += (double)m;
+    acc_l1 += (double)fabsf(sX[ly + SSIM_R][lx + SSIM_R] - sY[ly + SSIM_R][lx + SSIM_R]);
+    if (dm_mu1) {
+      const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+      const float w = counted ? 1.f : 0.f;   // cropped pixels get no gradient
+      dm_mu1[o] = w * (2.f * mu2 * D * iAB - 2.f * mu2 * Cc * iAB - 2.f * mu1 * Cc * D * iAB / A +
+                       2.f * mu1 * Cc * D * iAB / B);
+      dm_s1[o] = w * (-Cc * D * iAB / B);
+      dm_s12[o] = w * (2.f * Cc * iAB);
+    }
+  }
+  acc_ssim = wave_sum_f64(acc_ssim);
+  acc_l1 = wave_sum_f64(acc_l1);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = acc_ssim;
+    red[1][tid >> 6] = acc_l1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&sums[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// Backward: grad_img1 = w_l1 * sign(x - y) + w_ssim * ( G*dm_mu1 + 2x (G*dm_s1) + y (G*dm_s12) )
+// where w_ssim already carries d loss / d mean-ssim divided by the counted pixels.
+__global__ void __launch_bounds__(256)
+ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
+                const float *__restrict__ img2, ImgView v2, const float *__restrict__ dm_mu1,
+                const float *__restrict__ dm_s1, const float *__restrict__ dm_s12,
+                const float *__restrict__ weights /* device [2]: w_ssim, w_l1 */,
+                float *__restrict__ grad, ImgView vg) {
+  __shared__ float sM[3][SSIM_H][SSIM_H + 1];
+  __shared__ float sHz[3][SSIM_H][SSIM_T + 1];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + SSIM_T - 1) / SSIM_T;
+  const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+  const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
+  const int x0 = bx * SSIM_T - SSIM_R, y0 = by * SSIM_T - SSIM_R;
+  const float w_ssim = weights[0], w_l1 = weights[1];
+  for (int i = tid; i < SSIM_H * SSIM_H; i += 256) {
+    const int ly = i / SSIM_H, lx = i % SSIM_H;
+    const int gx = x0 + lx, gy = y0 + ly;
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (gx >= 0 && gy >= 0 && gx < W && gy < H) {
+      const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+      a = dm_mu1[o];
+      b = dm_s1[o];
+      d = dm_s12[o];
+    }
+    sM[0][ly][lx] = a;
+    sM[1][ly][lx] = b;
+    sM[2][ly][lx] = d;
+  }
+  __syncthreads();
+  for (int i = tid; i < SSIM_H * SSIM_T; i += 256) {
+    const int ly = i / SSIM_T, lx = i % SSIM_T;
+    float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = SSIM_G[k];
+      a = fmaf(g, sM[0][ly][lx + k], a);
+      b = fmaf(g, sM[1][ly][lx + k], b);
+      d = fmaf(g, sM[2][ly][lx + k], d);
+    }
+    sHz[0][ly][lx] = a;
+    sHz[1][ly][lx] = b;
+    sHz[2][ly][lx] = d;
+  }
+  __syncthreads();
+  for (int i = tid; i < SSIM_T * SSIM_T; i += 256) {
+    const int ly = i / SSIM_T, lx = i % SSIM_T;
+    const int gx = bx * SSIM_T + lx, gy = by * SSIM_T + ly;
+    if (gx >= W || gy >= H) continue;
+    float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float g = SSIM_G[k];
+      a = fmaf(g, sHz[0][ly + k][lx], a);
+      b = fmaf(g, sHz[1][ly + k][lx], b);
+      d = fmaf(g, sHz[2][ly + k][lx], d);
+    }
+    const float x = img1[n * v1.sn + c * v1.sc + gy * v1.sh + gx * v1.sw];
+    const float y = img2[n * v2.sn + c * v2.sc + gy * v2.sh + gx * v2.sw];
+    const float df = x - y;
+    const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+    grad[n * vg.sn + c * vg.sc + gy * vg.sh + gx * vg.sw] =
+        w_l1 * sgn + w_ssim * (a + 2.f * x * b + y * d);
+  }
+}
+
+}  // namespace gsr
+
+// img strides are in ELEMENTS for a logical [N, CH, H, W] image (pass the
+// strides of an NHWC tensor permuted to NCHW to consume it in place).
+// sums[2] (device, fp64, zeroed inside) = {sum of SSIM over the counted region,
+// sum |img1-img2| over all pixels}. dm_* [N,CH,H,W] may be NULL (no backward).
+extern "C" int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1,
+                               const int64_t *strides1, const float *img2,
+                               const int64_t *strides2, int valid_only, double *sums,
+                               float *dm_mu1, float *dm_s1, float *dm_s12, void *stream) {
+  GSR_REQUIRE(N > 0 && CH > 0 && H > 0 && W > 0, "ssim_l1_fwd: bad sizes");
+  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && sums, "ssim_l1_fwd: null pointer");
+  GSR_REQUIRE((dm_mu1 == nullptr) == (dm_s1 == nullptr) && (dm_s1 == nullptr) == (dm_s12 == nullptr),
+              "ssim_l1_fwd: pass all three derivative maps or none");
+  GSR_REQUIRE((int64_t)N * CH < 65536, "ssim_l1_fwd: too many planes");
+  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(double), (hipStream_t)stream));
+  gsr::ImgView v1{strides1[0], strides1[1], strides1[2], strides1[3]};
+  gsr::ImgView v2{strides2[0], strides2[1], strides2[2], strides2[3]};
+  dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
+  hipLaunchKernelGGL(gsr::ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
+                     img1, v1, img2, v2, valid_only, sums, dm_mu1, dm_s1, dm_s12);
+  GSR_CHECK_LAUNCH("ssim_l1_fwd");
+  return GSR_OK;
+}
+
+// grad (strides stridesg) = weights[1]*sign(img1-img2) + weights[0]*dSSIM/dimg1,
+// weights = device float[2] (so the upstream gradient never visits the host).
+extern "C" int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1,
+                               const int64_t *strides1, const float *img2,
+                               const int64_t *strides2, const float *dm_mu1, const float *dm_s1,
+                               const float *dm_s12, const float *weights, float *grad,
+                               const int64_t *stridesg, void *stream) {
+  GSR_REQUIRE(N > 0 && CH > 0 && H > 0 && W > 0, "ssim_l1_bwd: bad sizes");
+  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && dm_mu1 && dm_s1 && dm_s12 && weights &&
+                  grad && stridesg,
+              "ssim_l1_bwd: null pointer");
+  GSR_REQUIRE((int64_t)N * CH < 65536, "ssim_l1_bwd: too many planes");
+  gsr::ImgView v1{strides1[0], strides1[1], strides1[2], strides1[3]};
+  gsr::ImgView v2{strides2[0], strides2[1], strides2[2], strides2[3]};
+  gsr::ImgView vg{stridesg[0], stridesg[1], stridesg[2], stridesg[3]};
+  dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
+  hipLaunchKernelGGL(gsr::ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
+                     img1, v1, img2, v2, dm_mu1, dm_s1, dm_s12, weights, grad, vg);
+  GSR_CHECK_LAUNCH("ssim_l1_bwd");
+  return GSR_OK;
+}

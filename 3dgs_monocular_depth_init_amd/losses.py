@@ -1,0 +1,88 @@
+"""Fused training loss: L1 + SSIM in two HIP launches.
+
+`fused_ssim(img1, img2, padding=..., train=...)` keeps the call signature of the
+third-party op the reference imports (`from fused_ssim import fused_ssim`,
+/root/reference/gs_init_compare/runner.py:17, used at runner.py:507: NCHW
+inputs, 11x11 Gaussian window sigma 1.5, zero padding for the window,
+padding="valid" = mean over the map cropped by 5 px). `l1_ssim_loss` fuses the
+whole loss of runner.py:506-510 (forward: one launch, backward: one launch,
+instead of ~12 elementwise/conv kernels) and consumes the rasterizer's NHWC
+output in place.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from ._lib import call, ptr
+
+
+def _strides(t: Tensor):
+    return (C.c_int64 * 4)(*t.stride())
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _SsimL1(torch.autograd.Function):
+    """Returns (mean SSIM over the counted region, mean |a-b|) for logical NCHW views."""
+
+    @staticmethod
+    def forward(ctx, img1: Tensor, img2: Tensor, valid: bool, train: bool):
+        N, CH, H, W = img1.shape
+        dev = img1.device
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        need = train and img1.requires_grad
+        maps = torch.empty(3, N, CH, H, W, dtype=torch.float32, device=dev) if need else None
+        call("gsr_ssim_l1_fwd", N, CH, H, W, ptr(img1), _strides(img1), ptr(img2), _strides(img2),
+             int(valid), ptr(sums), ptr(maps[0]) if need else None, ptr(maps[1]) if need else None,
+             ptr(maps[2]) if need else None, _st())
+        hh, ww = (H - 10, W - 10) if valid else (H, W)
+        n_ssim = N * CH * max(hh, 0) * max(ww, 0)
+        n_l1 = N * CH * H * W
+        ctx.counts = (n_ssim, n_l1)
+        ctx.save_for_backward(img1, img2, maps)
+        out = sums / torch.tensor([max(n_ssim, 1), n_l1], dtype=torch.float64, device=dev)
+        return out[0].float(), out[1].float()
+
+    @staticmethod
+    def backward(ctx, v_ssim, v_l1):
+        img1, img2, maps = ctx.saved_tensors
+        if maps is None:
+            raise RuntimeError("fused_ssim was called with train=False; no backward available")
+        N, CH, H, W = img1.shape
+        n_ssim, n_l1 = ctx.counts
+        dev = img1.device
+        z = torch.zeros((), device=dev)
+        w = torch.stack([(v_ssim if v_ssim is not None else z) / max(n_ssim, 1),
+                         (v_l1 if v_l1 is not None else z) / n_l1]).float().contiguous()
+        grad = torch.empty_strided(img1.shape, img1.stride(), dtype=torch.float32, device=dev)
+        call("gsr_ssim_l1_bwd", N, CH, H, W, ptr(img1), _strides(img1), ptr(img2), _strides(img2),
+             ptr(maps[0]), ptr(maps[1]), ptr(maps[2]), ptr(w), ptr(grad), _strides(grad), _st())
+        return grad, None, None, None
+
+
+def _check(img1: Tensor, img2: Tensor):
+    if not (img1.is_cuda and img2.is_cuda):
+        from ._lib import GsrastError
+        raise GsrastError("fused_ssim: tensors must be on a ROCm device; there is no CPU path")
+    assert img1.shape == img2.shape and img1.dim() == 4, "expected [N,C,H,W]"
+    return img1.float(), img2.float()
+
+
+def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = True) -> Tensor:
+    """Mean SSIM of NCHW images (drop-in for fused_ssim.fused_ssim, runner.py:507)."""
+    assert padding in ("same", "valid")
+    img1, img2 = _check(img1, img2)
+    ssim, _ = _SsimL1.apply(img1, img2.detach(), padding == "valid", train)
+    return ssim
+
+
+def l1_ssim_loss(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    """runner.py:506-510 fused: colors / pixels are NHWC [C,H,W,3]."""
+    c, p = _check(colors.permute(0, 3, 1, 2), pixels.permute(0, 3, 1, 2))
+    ssim, l1 = _SsimL1.apply(c, p.detach(), True, True)
+    return l1 * (1.0 - ssim_lambda) + (1.0 - ssim) * ssim_lambda

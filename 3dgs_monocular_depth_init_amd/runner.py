@@ -155,14 +155,11 @@ def train_step(
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         render_mode="RGB")
     colors = renders[..., :3]
-    l1loss = torch.nn.functional.l1_loss(colors, pixels)                # runner.py:506
     if ssim_lambda > 0.0:
-        from .losses import fused_ssim
-        ssimloss = 1.0 - fused_ssim(colors.permute(0, 3, 1, 2), pixels.permute(0, 3, 1, 2),
-                                    padding="valid")
-        loss = l1loss * (1.0 - ssim_lambda) + ssimloss * ssim_lambda   # runner.py:510
+        from .losses import l1_ssim_loss                                 # runner.py:506-510 fused
+        loss = l1_ssim_loss(colors, pixels, ssim_lambda)
     else:
-        loss = l1loss
+        loss = torch.nn.functional.l1_loss(colors, pixels)              # runner.py:506
     loss.backward()                                                      # runner.py:547
     if grad_sync is not None:
         grad_sync()

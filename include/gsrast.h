@@ -168,6 +168,26 @@ int gsr_adam_step(int n, void *const *params, const void *const *grads, void *co
                   void *const *exp_avg_sq, const int64_t *numel, const float *step_size,
                   const float *bc2_sqrt, double beta1, double beta2, double eps, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * F1: fused L1 + SSIM loss (gs_init_compare/runner.py:506-510; replaces the
+ * third-party `fused_ssim`, setup.py:14). Images are logical [N,CH,H,W] fp32
+ * addressed by ELEMENT strides (HOST int64[4]), so NHWC renders are used in
+ * place. 11x11 Gaussian window (sigma 1.5), zero padding, C1=0.01^2, C2=0.03^2.
+ * fwd: sums[2] (device fp64, zeroed inside) = {sum SSIM over the counted
+ *      region (all pixels, or the map cropped by 5 px when valid_only),
+ *      sum |img1-img2|}; dm_* [N,CH,H,W] receive dSSIM/d{mu1,sigma1^2,sigma12}
+ *      (all three or all NULL).
+ * bwd: grad = weights[1]*sign(img1-img2) + weights[0]*dSSIM/dimg1 with
+ *      weights a device float[2].
+ * --------------------------------------------------------------------------*/
+int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1, const int64_t *strides1,
+                    const float *img2, const int64_t *strides2, int valid_only, double *sums,
+                    float *dm_mu1, float *dm_s1, float *dm_s12, void *stream);
+int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1, const int64_t *strides1,
+                    const float *img2, const int64_t *strides2, const float *dm_mu1,
+                    const float *dm_s1, const float *dm_s12, const float *weights, float *grad,
+                    const int64_t *stridesg, void *stream);
+
 /* Test hook: in [8][64] -> out[0..63] = per-lane result of the 8-value lane-swap
  * reduction tree used by gsr_rasterize_bwd, out[64..127] = wave sum of in[0],
  * idx_out[64] = which input each lane holds the total of. */
