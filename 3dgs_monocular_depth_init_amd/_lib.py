@@ -51,6 +51,8 @@ SIGNATURES.update({
     "gsr_depth_grad": [_i, _i, _p, _p, _p],
     "gsr_unproject_num_blocks": [_i, _i],
     "gsr_unproject_count": [_i, _i, _p, _p, _p, _p, _p, _p],
+    "gsr_m3d_preprocess": [_i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
+    "gsr_m3d_postprocess": [_i, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _p, _p],
     "gsr_unproject_emit": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 })
 OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)

@@ -308,6 +308,66 @@ unproject_emit_kernel(int H, int W, const float *__restrict__ depth,
   }
 }
 
+// ---------------------------------------------------------------- B10
+// Metric3D pre-processing (predictors/metric3d.py:42-83) fused into one pass:
+// float RGB [H,W,3] in [0,1] -> uint8 (truncation) -> channel flip ([:, :, ::-1]) ->
+// keep-ratio bilinear resize to (rh, rw) (half-pixel centres, result rounded to
+// uint8 like cv2.INTER_LINEAR) -> constant border (the mean colour, saturated to
+// uint8) up to (out_h, out_w) -> (x - mean) / std -> planar [3, out_h, out_w].
+__global__ void __launch_bounds__(256)
+m3d_preprocess_kernel(int H, int W, const float *__restrict__ img, int rh, int rw, int pad_top,
+                      int pad_left, int out_h, int out_w, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)out_h * out_w) return;
+  const int oy = (int)(i / out_w), ox = (int)(i - (int64_t)oy * out_w);
+  const float mean[3] = {123.675f, 116.28f, 103.53f}, stdv[3] = {58.395f, 57.12f, 57.375f};
+  const float border[3] = {124.f, 116.f, 104.f};   // cv2 saturate_cast<uchar> of the pad value
+  const int ry = oy - pad_top, rx = ox - pad_left;
+  float px[3];
+  if (ry < 0 || rx < 0 || ry >= rh || rx >= rw) {
+    px[0] = border[0]; px[1] = border[1]; px[2] = border[2];
+  } else {
+    const float sy = fmaxf(((float)ry + 0.5f) * ((float)H / (float)rh) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)rx + 0.5f) * ((float)W / (float)rw) - 0.5f, 0.f);
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int sc = 2 - c;   // [:, :, ::-1]
+      auto q = [&](int y, int x) { return floorf(img[((int64_t)y * W + x) * 3 + sc] * 255.0f); };
+      const float top = q(y0, x0) + (q(y0, x1) - q(y0, x0)) * fx;
+      const float bot = q(y1, x0) + (q(y1, x1) - q(y1, x0)) * fx;
+      px[c] = fminf(fmaxf(rintf(top + (bot - top) * fy), 0.f), 255.f);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(int64_t)c * out_h * out_w + i] = (px[c] - mean[c]) / stdv[c];
+}
+
+// Metric3D post-processing (metric3d.py:96-131) fused: un-pad, bilinear upsample
+// (F.interpolate, align_corners=False) to (H, W), * scale, clamp [lo, hi].
+__global__ void __launch_bounds__(256)
+m3d_postprocess_kernel(int in_h, int in_w, const float *__restrict__ in, int pad_top, int pad_bot,
+                       int pad_left, int pad_right, int H, int W, float scale, float lo, float hi,
+                       int do_clamp, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+  const int ch = in_h - pad_top - pad_bot, cw = in_w - pad_left - pad_right;
+  const float sy = fmaxf(((float)y + 0.5f) * ((float)ch / (float)H) - 0.5f, 0.f);
+  const float sx = fmaxf(((float)x + 0.5f) * ((float)cw / (float)W) - 0.5f, 0.f);
+  const int y0 = min((int)sy, ch - 1), x0 = min((int)sx, cw - 1);
+  const int y1 = min(y0 + 1, ch - 1), x1 = min(x0 + 1, cw - 1);
+  const float fy = sy - (float)y0, fx = sx - (float)x0;
+  auto q = [&](int yy, int xx) { return in[(int64_t)(yy + pad_top) * in_w + (xx + pad_left)]; };
+  const float v = (1.f - fy) * ((1.f - fx) * q(y0, x0) + fx * q(y0, x1)) +
+                  fy * ((1.f - fx) * q(y1, x0) + fx * q(y1, x1));
+  float r = v * scale;
+  if (do_clamp) r = fminf(fmaxf(r, lo), hi);
+  out[i] = r;
+}
+
 }  // namespace gsr
 
 #define ST ((hipStream_t)stream)
@@ -452,5 +512,33 @@ extern "C" int gsr_unproject_emit(int H, int W, const float *depth, const uint8_
                      0, ST, H, W, depth, valid, subsample, extra, rgb, Kinv, c2w, block_offsets,
                      pts, rgb_out, final_mask);
   GSR_CHECK_LAUNCH("unproject_emit");
+  return GSR_OK;
+}
+
+extern "C" int gsr_m3d_preprocess(int H, int W, const float *img, int rh, int rw, int pad_top,
+                                  int pad_left, int out_h, int out_w, float *out, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && rh > 0 && rw > 0 && out_h >= rh + pad_top && out_w >= rw + pad_left &&
+                  pad_top >= 0 && pad_left >= 0,
+              "m3d_preprocess: bad sizes");
+  GSR_REQUIRE(img && out, "m3d_preprocess: null pointer");
+  int64_t n = (int64_t)out_h * out_w;
+  hipLaunchKernelGGL(gsr::m3d_preprocess_kernel, dim3((unsigned)gsr::ceil_div64(n, 256)),
+                     dim3(256), 0, ST, H, W, img, rh, rw, pad_top, pad_left, out_h, out_w, out);
+  GSR_CHECK_LAUNCH("m3d_preprocess");
+  return GSR_OK;
+}
+
+extern "C" int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_top, int pad_bot,
+                                   int pad_left, int pad_right, int H, int W, float scale,
+                                   float lo, float hi, int do_clamp, float *out, void *stream) {
+  GSR_REQUIRE(in_h > pad_top + pad_bot && in_w > pad_left + pad_right && H > 0 && W > 0 &&
+                  pad_top >= 0 && pad_bot >= 0 && pad_left >= 0 && pad_right >= 0,
+              "m3d_postprocess: bad sizes");
+  GSR_REQUIRE(in && out, "m3d_postprocess: null pointer");
+  int64_t n = (int64_t)H * W;
+  hipLaunchKernelGGL(gsr::m3d_postprocess_kernel, dim3((unsigned)gsr::ceil_div64(n, 256)),
+                     dim3(256), 0, ST, in_h, in_w, in, pad_top, pad_bot, pad_left, pad_right, H, W,
+                     scale, lo, hi, do_clamp, out);
+  GSR_CHECK_LAUNCH("m3d_postprocess");
   return GSR_OK;
 }

@@ -1,0 +1,84 @@
+"""Metric3D v2 predictor: device pre/post-processing around
+an injected depth network.
+
+Mirror of /root/reference/gs_init_compare/depth_prediction/predictors/metric3d.py:18-139.
+The reference loads the network with `torch.hub.load("yvanyin/metric3d", ...,
+pretrain=True)` (lines 27-31): a remote fetch of code + weights that is not
+available offline, so the network is a constructor argument here -- any object
+with `inference({"input": x [1,3,616,1064]}) -> (depth [1,1,h,w], confidence,
+{"prediction_normal": [1,4,h,w]})`. Everything around it -- uint8 conversion,
+channel flip, keep-ratio resize (cv2.INTER_LINEAR on the CPU in the reference),
+mean-colour border, normalisation, un-padding, bilinear upsampling,
+de-canonicalisation (x fx/1000) and the [0,300] clamp -- runs in two fused
+kernels on the device, without the reference's device->host->device round trip.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..._lib import call, ptr
+from .depth_predictor_interface import CameraIntrinsics, DepthPredictor, PredictedDepth
+
+INPUT_SIZE = (616, 1064)          # metric3d.py:47 (ViT models)
+CANONICAL_FOCAL = 1000.0          # metric3d.py:127-129
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def preprocess(img: torch.Tensor):
+    """img float [H,W,3] in [0,1] on the device -> (net input [1,3,616,1064], pad_info, scale)."""
+    H, W = img.shape[:2]
+    scale = min(INPUT_SIZE[0] / H, INPUT_SIZE[1] / W)                 # :49
+    rh, rw = int(H * scale), int(W * scale)                           # :50-52
+    pad_h, pad_w = INPUT_SIZE[0] - rh, INPUT_SIZE[1] - rw             # :62-65
+    pad_info = [pad_h // 2, pad_h - pad_h // 2, pad_w // 2, pad_w - pad_w // 2]
+    out = torch.empty(1, 3, *INPUT_SIZE, dtype=torch.float32, device=img.device)
+    img = img.contiguous().float()
+    call("gsr_m3d_preprocess", H, W, ptr(img), rh, rw, pad_info[0], pad_info[2], INPUT_SIZE[0],
+         INPUT_SIZE[1], ptr(out), _st())
+    return out, pad_info, scale
+
+
+def to_og_size(t: torch.Tensor, pad_info, size, scale: float = 1.0, clamp=None) -> torch.Tensor:
+    """metric3d.py:96-118 for one [h,w] map (+ optional scale / clamp, :127-131)."""
+    t = t.contiguous().float()
+    H, W = size
+    out = torch.empty(H, W, dtype=torch.float32, device=t.device)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    call("gsr_m3d_postprocess", t.shape[0], t.shape[1], ptr(t), pad_info[0], pad_info[1],
+         pad_info[2], pad_info[3], H, W, float(scale), float(lo), float(hi), int(clamp is not None),
+         ptr(out), _st())
+    return out
+
+
+class Metric3d(DepthPredictor):
+    def __init__(self, config, device: str, model=None, backbone: str = "vits"):
+        if model is None:
+            raise RuntimeError(
+                "Metric3d needs a depth network: the reference fetches it with torch.hub "
+                "(metric3d.py:27-31), which is unavailable offline; pass model=<network>")
+        self.__name = f"Metric3d_{backbone}"
+        self.__model = model
+        self.device = device
+
+    @property
+    def name(self) -> str:
+        return self.__name
+
+    @torch.no_grad()
+    def predict_depth(self, img: torch.Tensor, intrinsics: CameraIntrinsics) -> PredictedDepth:
+        img = img.to(self.device)
+        H, W = img.shape[:2]
+        rgb, pad_info, scale = preprocess(img)
+        pred_depth, confidence, output_dict = self.__model.inference({"input": rgb})
+        normal = output_dict["prediction_normal"]
+        fx_scaled = intrinsics.fx * scale                                   # :54-59
+        depth = to_og_size(pred_depth.squeeze(), pad_info, (H, W),
+                           scale=fx_scaled / CANONICAL_FOCAL, clamp=(0.0, 300.0))   # :127-131
+        conf = to_og_size(confidence.squeeze(), pad_info, (H, W))
+        n = torch.stack([to_og_size(normal[0, k], pad_info, (H, W)) for k in range(3)], dim=-1)
+        n_conf = to_og_size(normal[0, 3], pad_info, (H, W))
+        return PredictedDepth(depth=depth, mask=torch.ones_like(depth, dtype=torch.bool),
+                              depth_confidence=conf, normal=n, normal_confidence=n_conf)

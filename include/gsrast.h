@@ -261,6 +261,18 @@ int gsr_unproject_emit(int H, int W, const float *depth, const uint8_t *valid,
                        const float *Kinv, const float *c2w, const int32_t *block_offsets,
                        float *pts, float *rgb_out, uint8_t *final_mask, void *stream);
 
+/* B10: Metric3D pre/post-processing (depth_prediction/predictors/metric3d.py:42-83,
+ * 96-131) around the depth network. preprocess: float RGB [H,W,3] in [0,1] ->
+ * uint8, channel flip, bilinear resize to (rh,rw), mean-colour border to
+ * (out_h,out_w), (x-mean)/std, planar [3,out_h,out_w]. postprocess: un-pad one
+ * [in_h,in_w] map, bilinear upsample (align_corners=False) to (H,W), * scale,
+ * optional clamp to [lo,hi]. */
+int gsr_m3d_preprocess(int H, int W, const float *img, int rh, int rw, int pad_top, int pad_left,
+                       int out_h, int out_w, float *out, void *stream);
+int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_top, int pad_bot,
+                        int pad_left, int pad_right, int H, int W, float scale, float lo, float hi,
+                        int do_clamp, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,3 +275,39 @@ def knn_dists(x: Tensor, K: int = 4) -> Tensor:
     (self included at distance 0), utils/runner_utils.py:142-146."""
     d = torch.cdist(x.double(), x.double())
     return torch.sort(d, dim=1).values[:, :K].to(x.dtype)
+
+
+# ---- B10: depth_prediction/predictors/metric3d.py:42-83, 96-131 --------------
+# PARITY UNPINNED: cv2 is absent, so the keep-ratio resize (cv2.INTER_LINEAR on
+# uint8, metric3d.py:50-52) is restated as bilinear interpolation at half-pixel
+# centres rounded to uint8; OpenCV's fixed-point weights can differ by 1 LSB.
+def metric3d_preprocess(img: Tensor, input_size=(616, 1064)):
+    """img float [H,W,3] in [0,1] -> (net input [1,3,616,1064], pad_info, scale)."""
+    import torch.nn.functional as F
+    rgb_origin = (img * 255.0).numpy().astype(np.uint8)[:, :, ::-1]            # :44
+    h, w = rgb_origin.shape[:2]
+    scale = min(input_size[0] / h, input_size[1] / w)                           # :49
+    rh, rw = int(h * scale), int(w * scale)
+    src = torch.from_numpy(rgb_origin.copy()).float().permute(2, 0, 1)[None]
+    rgb = F.interpolate(src, size=(rh, rw), mode="bilinear", align_corners=False)[0]
+    rgb = torch.clamp(torch.round(rgb), 0, 255)                                  # uint8 result
+    pad_h, pad_w = input_size[0] - rh, input_size[1] - rw
+    pad_info = [pad_h // 2, pad_h - pad_h // 2, pad_w // 2, pad_w - pad_w // 2]
+    border = torch.tensor([124.0, 116.0, 104.0])                                 # saturate_cast<uchar>
+    out = border[:, None, None].repeat(1, *input_size)
+    out[:, pad_info[0]:pad_info[0] + rh, pad_info[2]:pad_info[2] + rw] = rgb
+    mean = torch.tensor([123.675, 116.28, 103.53])[:, None, None]               # :79-83
+    std = torch.tensor([58.395, 57.12, 57.375])[:, None, None]
+    return ((out - mean) / std)[None], pad_info, scale
+
+
+def metric3d_to_og_size(t: Tensor, pad_info, size):
+    """metric3d.py:96-118 for a [h,w] map."""
+    import torch.nn.functional as F
+    t = t[pad_info[0]: t.shape[0] - pad_info[1], pad_info[2]: t.shape[1] - pad_info[3]]
+    return F.interpolate(t[None, None], size, mode="bilinear").squeeze()
+
+
+def metric3d_postprocess_depth(pred_depth: Tensor, pad_info, size, fx: float, scale: float):
+    d = metric3d_to_og_size(pred_depth, pad_info, size)
+    return torch.clamp(d * (fx * scale / 1000.0), 0, 300)                        # :127-131

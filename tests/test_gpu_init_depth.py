@@ -247,3 +247,45 @@ def test_c3_full_size_properties():
     # applying the mask twice changes nothing (idempotence)
     sub2 = S.StaticDepthSubsampler(10).get_mask(None, depth, sub.view(H, W))
     assert torch.equal(sub2, sub)
+
+
+class _FakeMetric3dNet:
+    """Stand-in for the torch.hub network (remote weights): a deterministic
+    function of the pre-processed input so the whole predictor can be compared."""
+
+    def inference(self, data):
+        x = data["input"]                                    # [1,3,616,1064]
+        depth = (x.mean(1, keepdim=True) * 0.7 + 3.0)
+        conf = torch.sigmoid(x[:, :1])
+        normal = torch.cat([x, x[:, :1] * 0.5], 1)
+        return depth, conf, {"prediction_normal": normal}
+
+
+@pytest.mark.parametrize("size", [(270, 480), (480, 360), (1080, 1920)])
+def test_metric3d_pre_post_processing_vs_oracle(size):
+    M = mod("depth_prediction.predictors.metric3d")
+    ifc = mod("depth_prediction.predictors.depth_predictor_interface")
+    H, W = size
+    g = torch.Generator().manual_seed(4)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    img = (torch.stack([xx, yy, 1 - xx], -1) * 0.8 + 0.2 * torch.rand(H, W, 3, generator=g)).clamp(0, 1)
+    net_in, pad_info, scale = M.preprocess(img.cuda())
+    ref_in, ref_pad, ref_scale = IO.metric3d_preprocess(img)
+    assert pad_info == ref_pad and scale == ref_scale and net_in.shape == (1, 3, 616, 1064)
+    diff = (net_in.cpu() - ref_in).abs()
+    one_lsb = 1.0 / 57.0
+    assert diff.max() <= one_lsb * 1.01                      # at most one uint8 step (rounding ties)
+    assert (diff > 1e-5).float().mean() < 2e-3
+    K = torch.tensor([[0.9 * W, 0, W / 2], [0, 0.9 * W, H / 2], [0, 0, 1.0]])
+    pred = M.Metric3d(None, "cuda", model=_FakeMetric3dNet()).predict_depth(img.cuda(), ifc.CameraIntrinsics(K))
+    d_ref, c_ref, o_ref = _FakeMetric3dNet().inference({"input": net_in.cpu()})
+    depth_ref = IO.metric3d_postprocess_depth(d_ref.squeeze(), pad_info, (H, W), float(K[0, 0]), scale)
+    assert pred.depth.shape == (H, W) and pred.mask.all() and pred.mask.dtype == torch.bool
+    assert torch.allclose(pred.depth.cpu(), depth_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(pred.depth_confidence.cpu(),
+                          IO.metric3d_to_og_size(c_ref.squeeze(), pad_info, (H, W)), rtol=1e-5, atol=1e-5)
+    n_ref = torch.stack([IO.metric3d_to_og_size(o_ref["prediction_normal"][0, k], pad_info, (H, W))
+                         for k in range(3)], -1)
+    assert pred.normal.shape == (H, W, 3) and torch.allclose(pred.normal.cpu(), n_ref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        M.Metric3d(None, "cuda")                              # no silent torch.hub fetch
