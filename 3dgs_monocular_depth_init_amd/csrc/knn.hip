@@ -1,0 +1,171 @@
+// knn.hip -- F3 / A9: exact K-nearest-neighbour distances for the initial scales.
+//
+// Replaces `knn(points, 4)` = sklearn NearestNeighbors on the CPU
+// (gs_init_compare/utils/runner_utils.py:142-146), called from
+// create_splats_with_optimizers (runner.py:88-91) and the scale clamp of
+// monocular_depth_init.py:215-223, with 0.3-2 M points.
+//
+// Points are bucketed into cubic cells of edge h (64-bit cell keys, sorted; the
+// caller sorts with torch and passes unique keys + start offsets). One thread
+// per query walks the cells ring by ring (Chebyshev radius r = 1, 2, ...) and
+// keeps the K smallest squared distances in registers; it stops as soon as the
+// K-th distance is <= r*h, which no point outside the visited cube can beat
+// (exact result, not approximate). Cell lookups are binary searches in the
+// sorted unique-key array, so memory is O(N) whatever the extent of the cloud.
+#include "common.h"
+
+namespace gsr {
+
+constexpr int KNN_MAX_K = 8;
+
+__device__ __forceinline__ uint64_t cell_key(int ix, int iy, int iz) {
+  // 21 bits per axis (coordinates are offset to be non-negative by the caller)
+  return ((uint64_t)(uint32_t)ix << 42) | ((uint64_t)(uint32_t)iy << 21) | (uint64_t)(uint32_t)iz;
+}
+
+__global__ void __launch_bounds__(256)
+knn_cell_keys_kernel(int N, const float *__restrict__ pts, const float *__restrict__ origin,
+                     float inv_h, int64_t *__restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int ix = (int)floorf((pts[i * 3 + 0] - origin[0]) * inv_h);
+  const int iy = (int)floorf((pts[i * 3 + 1] - origin[1]) * inv_h);
+  const int iz = (int)floorf((pts[i * 3 + 2] - origin[2]) * inv_h);
+  keys[i] = (int64_t)cell_key(max(ix, 0), max(iy, 0), max(iz, 0));
+}
+
+template <int K>
+__device__ __forceinline__ void topk_insert(float (&best)[K], float d2) {
+  if (d2 >= best[K - 1]) return;
+  best[K - 1] = d2;
+#pragma unroll
+  for (int j = K - 1; j > 0; --j) {
+    if (best[j] < best[j - 1]) {
+      const float t = best[j];
+      best[j] = best[j - 1];
+      best[j - 1] = t;
+    }
+  }
+}
+
+// sorted_pts: points permuted into cell order; order[i] = original index of sorted point i.
+template <int K>
+__global__ void __launch_bounds__(128)
+knn_grid_kernel(int N, const float *__restrict__ sorted_pts, const int64_t *__restrict__ order,
+                const int64_t *__restrict__ ukeys, const int64_t *__restrict__ ustart, int U,
+                const float *__restrict__ origin, float h, int max_ring,
+                float *__restrict__ out /* [N,K] distances, original order */) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float px = sorted_pts[i * 3], py = sorted_pts[i * 3 + 1], pz = sorted_pts[i * 3 + 2];
+  const float inv_h = 1.0f / h;
+  const int cx = max((int)floorf((px - origin[0]) * inv_h), 0);
+  const int cy = max((int)floorf((py - origin[1]) * inv_h), 0);
+  const int cz = max((int)floorf((pz - origin[2]) * inv_h), 0);
+  float best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = 3.0e38f;
+  for (int r = 0; r <= max_ring; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      for (int dy = -r; dy <= r; ++dy) {
+        const bool face = (abs(dz) == r) || (abs(dy) == r);
+        for (int dx = -r; dx <= r; dx += (face ? 1 : max(2 * r, 1))) {   // shell only
+          const int x = cx + dx, y = cy + dy, z = cz + dz;
+          if (x < 0 || y < 0 || z < 0) continue;
+          const int64_t key = (int64_t)cell_key(x, y, z);
+          int lo = 0, hi = U;                 // lower_bound(ukeys, key)
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          if (lo >= U || ukeys[lo] != key) continue;
+          const int64_t s = ustart[lo], e = ustart[lo + 1];
+          for (int64_t j = s; j < e; ++j) {
+            const float ddx = sorted_pts[j * 3] - px, ddy = sorted_pts[j * 3 + 1] - py,
+                        ddz = sorted_pts[j * 3 + 2] - pz;
+            topk_insert<K>(best, ddx * ddx + ddy * ddy + ddz * ddz);
+          }
+        }
+      }
+    }
+    const float reach = (float)r * h;          // everything nearer than this has been seen
+    if (r >= 1 && best[K - 1] <= reach * reach) break;
+  }
+  const int64_t o = order[i];
+#pragma unroll
+  for (int j = 0; j < K; ++j) out[o * K + j] = sqrtf(best[j]);
+}
+
+// Brute force: one workgroup per query, used to size the grid cell from a sample
+// and as the small-N path.
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_brute_kernel(int Q, int N, const float *__restrict__ queries, const float *__restrict__ pts,
+                 float *__restrict__ out /* [Q,K] */) {
+  __shared__ float sbest[256][K];
+  const int q = blockIdx.x;
+  const float px = queries[q * 3], py = queries[q * 3 + 1], pz = queries[q * 3 + 2];
+  float best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = 3.0e38f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const float dx = pts[j * 3] - px, dy = pts[j * 3 + 1] - py, dz = pts[j * 3 + 2] - pz;
+    topk_insert<K>(best, dx * dx + dy * dy + dz * dz);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) sbest[threadIdx.x][j] = best[j];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < 256; ++t)
+      for (int j = 0; j < K; ++j) topk_insert<K>(best, sbest[t][j]);
+    for (int j = 0; j < K; ++j) out[q * K + j] = sqrtf(best[j]);
+  }
+}
+
+}  // namespace gsr
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int gsr_knn_cell_keys(int N, const float *pts, const float *origin, float h,
+                                 int64_t *keys, void *stream) {
+  GSR_REQUIRE(N >= 0 && h > 0.f, "knn_cell_keys: bad arguments");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(pts && origin && keys, "knn_cell_keys: null pointer");
+  hipLaunchKernelGGL(gsr::knn_cell_keys_kernel, dim3(gsr::ceil_div(N, 256)), dim3(256), 0, ST, N,
+                     pts, origin, 1.0f / h, keys);
+  GSR_CHECK_LAUNCH("knn_cell_keys");
+  return GSR_OK;
+}
+
+extern "C" int gsr_knn_grid(int N, int K, const float *sorted_pts, const int64_t *order,
+                            const int64_t *ukeys, const int64_t *ustart, int U,
+                            const float *origin, float h, int max_ring, float *out,
+                            void *stream) {
+  GSR_REQUIRE(N >= 0 && U >= 0 && h > 0.f && max_ring >= 1, "knn_grid: bad arguments");
+  GSR_REQUIRE(K == 4 || K == 8, "knn_grid: K=%d (built for 4 and 8)", K);
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(sorted_pts && order && ukeys && ustart && origin && out, "knn_grid: null pointer");
+  dim3 grid(gsr::ceil_div(N, 128));
+  if (K == 4)
+    hipLaunchKernelGGL(gsr::knn_grid_kernel<4>, grid, dim3(128), 0, ST, N, sorted_pts, order, ukeys,
+                       ustart, U, origin, h, max_ring, out);
+  else
+    hipLaunchKernelGGL(gsr::knn_grid_kernel<8>, grid, dim3(128), 0, ST, N, sorted_pts, order, ukeys,
+                       ustart, U, origin, h, max_ring, out);
+  GSR_CHECK_LAUNCH("knn_grid");
+  return GSR_OK;
+}
+
+extern "C" int gsr_knn_brute(int Q, int N, int K, const float *queries, const float *pts,
+                             float *out, void *stream) {
+  GSR_REQUIRE(Q >= 0 && N >= 0, "knn_brute: bad sizes");
+  GSR_REQUIRE(K == 4 || K == 8, "knn_brute: K=%d (built for 4 and 8)", K);
+  if (Q == 0) return GSR_OK;
+  GSR_REQUIRE(queries && pts && out, "knn_brute: null pointer");
+  if (K == 4)
+    hipLaunchKernelGGL(gsr::knn_brute_kernel<4>, dim3(Q), dim3(256), 0, ST, Q, N, queries, pts, out);
+  else
+    hipLaunchKernelGGL(gsr::knn_brute_kernel<8>, dim3(Q), dim3(256), 0, ST, Q, N, queries, pts, out);
+  GSR_CHECK_LAUNCH("knn_brute");
+  return GSR_OK;
+}

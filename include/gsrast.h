@@ -261,6 +261,22 @@ int gsr_unproject_emit(int H, int W, const float *depth, const uint8_t *valid,
                        const float *Kinv, const float *c2w, const int32_t *block_offsets,
                        float *pts, float *rgb_out, uint8_t *final_mask, void *stream);
 
+/* F3 / A9: exact K-nearest-neighbour DISTANCES (K = 4 or 8, the point itself
+ * included), replacing sklearn's NearestNeighbors of utils/runner_utils.py:142-146.
+ * gsr_knn_cell_keys: 64-bit cell key of every point for cubic cells of edge h
+ *   (origin = per-axis minimum, device float[3]).
+ * gsr_knn_grid: points sorted by key (sorted_pts [N,3], order[N] = original
+ *   index), unique keys ukeys[U] with start offsets ustart[U+1]; ring-by-ring
+ *   exact search; out[N,K] in ORIGINAL order, ascending.
+ * gsr_knn_brute: Q queries against all N points (one workgroup per query). */
+int gsr_knn_cell_keys(int N, const float *pts, const float *origin, float h, int64_t *keys,
+                      void *stream);
+int gsr_knn_grid(int N, int K, const float *sorted_pts, const int64_t *order,
+                 const int64_t *ukeys, const int64_t *ustart, int U, const float *origin, float h,
+                 int max_ring, float *out, void *stream);
+int gsr_knn_brute(int Q, int N, int K, const float *queries, const float *pts, float *out,
+                  void *stream);
+
 /* B10: Metric3D pre/post-processing (depth_prediction/predictors/metric3d.py:42-83,
  * 96-131) around the depth network. preprocess: float RGB [H,W,3] in [0,1] ->
  * uint8, channel flip, bilinear resize to (rh,rw), mean-colour border to
