@@ -10,7 +10,9 @@
 // per query walks the cells ring by ring (Chebyshev radius r = 1, 2, ...) and
 // keeps the K smallest squared distances in registers; it stops as soon as the
 // K-th distance is <= r*h, which no point outside the visited cube can beat
-// (exact result, not approximate). Cell lookups are binary searches in the
+// (exact result, not approximate). The ring radius is capped (cost grows as
+// r^3): queries not proven exact within the cap -- isolated points -- are
+// flagged and finished by the brute-force kernel. Cell lookups are binary searches in the
 // sorted unique-key array, so memory is O(N) whatever the extent of the cloud.
 #include "common.h"
 
@@ -48,21 +50,24 @@ __device__ __forceinline__ void topk_insert(float (&best)[K], float d2) {
   }
 }
 
-// sorted_pts: points permuted into cell order; order[i] = original index of sorted point i.
+// N queries (queries[i], result row order[i]) against the points in cell order (sorted_pts).
 template <int K>
 __global__ void __launch_bounds__(128)
-knn_grid_kernel(int N, const float *__restrict__ sorted_pts, const int64_t *__restrict__ order,
+knn_grid_kernel(int N, const float *__restrict__ queries, const float *__restrict__ sorted_pts,
+                const int64_t *__restrict__ order,
                 const int64_t *__restrict__ ukeys, const int64_t *__restrict__ ustart, int U,
                 const float *__restrict__ origin, float h, int max_ring,
-                float *__restrict__ out /* [N,K] distances, original order */) {
+                float *__restrict__ out /* [N,K] distances, original order */,
+                uint8_t *__restrict__ unresolved /* [N] original order: 1 = not proven exact */) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float px = sorted_pts[i * 3], py = sorted_pts[i * 3 + 1], pz = sorted_pts[i * 3 + 2];
+  const float px = queries[i * 3], py = queries[i * 3 + 1], pz = queries[i * 3 + 2];
   const float inv_h = 1.0f / h;
   const int cx = max((int)floorf((px - origin[0]) * inv_h), 0);
   const int cy = max((int)floorf((py - origin[1]) * inv_h), 0);
   const int cz = max((int)floorf((pz - origin[2]) * inv_h), 0);
   float best[K];
+  bool proven = false;
 #pragma unroll
   for (int j = 0; j < K; ++j) best[j] = 3.0e38f;
   for (int r = 0; r <= max_ring; ++r) {
@@ -89,9 +94,13 @@ knn_grid_kernel(int N, const float *__restrict__ sorted_pts, const int64_t *__re
       }
     }
     const float reach = (float)r * h;          // everything nearer than this has been seen
-    if (r >= 1 && best[K - 1] <= reach * reach) break;
+    if (r >= 1 && best[K - 1] <= reach * reach) {
+      proven = true;
+      break;
+    }
   }
   const int64_t o = order[i];
+  unresolved[o] = proven ? 0 : 1;              // isolated points: finished by the brute-force pass
 #pragma unroll
   for (int j = 0; j < K; ++j) out[o * K + j] = sqrtf(best[j]);
 }
@@ -137,21 +146,26 @@ extern "C" int gsr_knn_cell_keys(int N, const float *pts, const float *origin, f
   return GSR_OK;
 }
 
-extern "C" int gsr_knn_grid(int N, int K, const float *sorted_pts, const int64_t *order,
+extern "C" int gsr_knn_grid(int N, int K, const float *queries, const float *sorted_pts,
+                            const int64_t *order,
                             const int64_t *ukeys, const int64_t *ustart, int U,
                             const float *origin, float h, int max_ring, float *out,
-                            void *stream) {
+                            uint8_t *unresolved, void *stream) {
   GSR_REQUIRE(N >= 0 && U >= 0 && h > 0.f && max_ring >= 1, "knn_grid: bad arguments");
   GSR_REQUIRE(K == 4 || K == 8, "knn_grid: K=%d (built for 4 and 8)", K);
   if (N == 0) return GSR_OK;
-  GSR_REQUIRE(sorted_pts && order && ukeys && ustart && origin && out, "knn_grid: null pointer");
+  GSR_REQUIRE(queries && sorted_pts && order && ukeys && ustart && origin && out && unresolved,
+              "knn_grid: null pointer");
+  GSR_REQUIRE(max_ring <= 8, "knn_grid: max_ring %d > 8 (ring cost grows as r^3)", max_ring);
   dim3 grid(gsr::ceil_div(N, 128));
   if (K == 4)
-    hipLaunchKernelGGL(gsr::knn_grid_kernel<4>, grid, dim3(128), 0, ST, N, sorted_pts, order, ukeys,
-                       ustart, U, origin, h, max_ring, out);
+    hipLaunchKernelGGL(gsr::knn_grid_kernel<4>, grid, dim3(128), 0, ST, N, queries, sorted_pts, order,
+                       ukeys,
+                       ustart, U, origin, h, max_ring, out, unresolved);
   else
-    hipLaunchKernelGGL(gsr::knn_grid_kernel<8>, grid, dim3(128), 0, ST, N, sorted_pts, order, ukeys,
-                       ustart, U, origin, h, max_ring, out);
+    hipLaunchKernelGGL(gsr::knn_grid_kernel<8>, grid, dim3(128), 0, ST, N, queries, sorted_pts, order,
+                       ukeys,
+                       ustart, U, origin, h, max_ring, out, unresolved);
   GSR_CHECK_LAUNCH("knn_grid");
   return GSR_OK;
 }

@@ -44,17 +44,52 @@ def knn(x: Tensor, K: int = 4) -> Tensor:
     extent = float((hi - lo).max())
     h = max(2.0 * float(sd[:, K - 1].median()), extent / 2.0e6, 1e-12)
     origin = lo.contiguous()
-    keys = torch.empty(N, dtype=torch.int64, device=pts.device)
+    pending = torch.arange(N, device=pts.device)
+    for attempt in range(3):
+        qpts = pts if attempt == 0 else pts[pending].contiguous()
+        _grid_pass(pts, qpts, pending if attempt else None, origin, h, K, out)
+        pending = torch.nonzero(_UNRESOLVED[0]).reshape(-1) if attempt == 0 else \
+            pending[torch.nonzero(_UNRESOLVED[0]).reshape(-1)]
+        if pending.numel() <= max(64, N // 200):
+            break
+        h *= 4.0                                   # sparse regions: retry those with coarser cells
+    if pending.numel() > 0:                        # isolated points: exact brute force
+        q = pts[pending].contiguous()
+        res = torch.empty(q.shape[0], K, dtype=torch.float32, device=pts.device)
+        call("gsr_knn_brute", q.shape[0], N, K, ptr(q), ptr(pts), ptr(res), _st())
+        out[pending] = res
+    return out.to(x.dtype)
+
+
+_UNRESOLVED = [None]
+MAX_RING = 3
+
+
+def _grid_pass(pts: Tensor, queries: Tensor, query_ids, origin: Tensor, h: float, K: int, out: Tensor):
+    """Bucket ALL points into cells of edge h and answer `queries` (all points on the
+    first pass, the still-unresolved ones afterwards) with the ring search."""
+    N = pts.shape[0]
+    dev = pts.device
+    keys = torch.empty(N, dtype=torch.int64, device=dev)
     call("gsr_knn_cell_keys", N, ptr(pts), ptr(origin), h, ptr(keys), _st())
     skeys, order = torch.sort(keys)
     sorted_pts = pts[order].contiguous()
     ukeys, counts = torch.unique_consecutive(skeys, return_counts=True)
-    ustart = torch.zeros(ukeys.numel() + 1, dtype=torch.int64, device=pts.device)
+    ustart = torch.zeros(ukeys.numel() + 1, dtype=torch.int64, device=dev)
     ustart[1:] = torch.cumsum(counts, 0)
-    max_ring = int(math.ceil(extent / h)) + 1
-    call("gsr_knn_grid", N, K, ptr(sorted_pts), ptr(order), ptr(ukeys), ptr(ustart),
-         int(ukeys.numel()), ptr(origin), h, max_ring, ptr(out), _st())
-    return out.to(x.dtype)
+    if query_ids is None:
+        q, qorder, Q = sorted_pts, order, N
+        res, unresolved = out, torch.empty(N, dtype=torch.uint8, device=dev)
+    else:
+        Q = queries.shape[0]
+        q, qorder = queries, torch.arange(Q, device=dev)
+        res = torch.empty(Q, K, dtype=torch.float32, device=dev)
+        unresolved = torch.empty(Q, dtype=torch.uint8, device=dev)
+    call("gsr_knn_grid", Q, K, ptr(q), ptr(sorted_pts), ptr(qorder), ptr(ukeys), ptr(ustart), int(ukeys.numel()),
+         ptr(origin), h, MAX_RING, ptr(res), ptr(unresolved), _st())
+    if query_ids is not None:
+        out[query_ids] = res
+    _UNRESOLVED[0] = unresolved
 
 
 def initial_log_scales(points: Tensor, init_scale: float = 1.0) -> Tensor:

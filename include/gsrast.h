@@ -265,15 +265,18 @@ int gsr_unproject_emit(int H, int W, const float *depth, const uint8_t *valid,
  * included), replacing sklearn's NearestNeighbors of utils/runner_utils.py:142-146.
  * gsr_knn_cell_keys: 64-bit cell key of every point for cubic cells of edge h
  *   (origin = per-axis minimum, device float[3]).
- * gsr_knn_grid: points sorted by key (sorted_pts [N,3], order[N] = original
- *   index), unique keys ukeys[U] with start offsets ustart[U+1]; ring-by-ring
- *   exact search; out[N,K] in ORIGINAL order, ascending.
+ * gsr_knn_grid: N queries against the points sorted by key (sorted_pts), unique
+ *   keys ukeys[U] with start offsets ustart[U+1] into sorted_pts; ring-by-ring
+ *   exact search up to max_ring (<= 8) rings; out[N,K] in ORIGINAL order,
+ *   ascending; unresolved[N] = 1 for queries whose result is not proven exact
+ *   within max_ring (finish those with gsr_knn_brute).
  * gsr_knn_brute: Q queries against all N points (one workgroup per query). */
 int gsr_knn_cell_keys(int N, const float *pts, const float *origin, float h, int64_t *keys,
                       void *stream);
-int gsr_knn_grid(int N, int K, const float *sorted_pts, const int64_t *order,
+int gsr_knn_grid(int N, int K, const float *queries /* [N,3] */, const float *sorted_pts,
+                 const int64_t *order /* result row of query i */,
                  const int64_t *ukeys, const int64_t *ustart, int U, const float *origin, float h,
-                 int max_ring, float *out, void *stream);
+                 int max_ring, float *out, uint8_t *unresolved, void *stream);
 int gsr_knn_brute(int Q, int N, int K, const float *queries, const float *pts, float *out,
                   void *stream);
 
