@@ -144,6 +144,8 @@ def train_step(
     cfg: RasterConfig = RasterConfig(),
     ssim_lambda: float = 0.0,
     grad_sync=None,          # callable run between backward and optimizer.step (all-reduce)
+    strategy=None,           # strategy.DefaultStrategy (runner.py:497-503, 639-647)
+    strategy_state=None,
 ) -> Tuple[Tensor, Dict]:
     """One iteration of Runner.train's body (runner.py:464-547, 676-689):
     SH-degree schedule, render, L1 (+ optional SSIM term), backward,
@@ -155,6 +157,8 @@ def train_step(
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         render_mode="RGB")
     colors = renders[..., :3]
+    if strategy is not None:
+        strategy.step_pre_backward(splats, optimizers, strategy_state, step, info)   # runner.py:497
     if ssim_lambda > 0.0:
         from .losses import l1_ssim_loss                                 # runner.py:506-510 fused
         loss = l1_ssim_loss(colors, pixels, ssim_lambda)
@@ -163,6 +167,8 @@ def train_step(
     loss.backward()                                                      # runner.py:547
     if grad_sync is not None:
         grad_sync()
+    if strategy is not None:                                             # runner.py:639-647
+        strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
     if optimizers is not None:
         if hasattr(optimizers, "step"):                                  # FusedAdam: one launch
             optimizers.step()

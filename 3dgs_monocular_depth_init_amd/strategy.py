@@ -1,0 +1,254 @@
+"""Densification strategy: the step either side of the rasterizer.
+
+`DefaultStrategy` keeps the interface the reference drives
+(/root/reference/gs_init_compare/runner.py:208-217 `check_sanity` /
+`initialize_state`, :497-503 `step_pre_backward`, :639-647
+`step_post_backward`; defaults scaled by config.py:204-221) -- i.e. gsplat's
+`gsplat.strategy.DefaultStrategy`, third-party and absent here (parity unpinned:
+restated from gsplat's published behaviour).
+
+What it consumes from the hot path: `info["means2d"].grad` (pixel-space
+gradient of the 2-D means, populated because `rasterization()` returns
+`means2d` as an autograd intermediate), `info["radii"]`, `width`, `height`,
+`n_cameras`.
+
+Multi-GPU replicas (distributed.py): every rank must take the SAME
+densification decisions, so the accumulated statistics are all-reduced before
+use and the split noise comes from a generator seeded identically on all ranks
+(the reference seeds ranks differently, runner.py:147 -- right for its
+Gaussian-sharded scheme, wrong for replicas).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def _quat_to_rotmat(q: Tensor) -> Tensor:
+    q = torch.nn.functional.normalize(q, dim=-1)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+def _opt_of(optimizers, name):
+    return optimizers[name]
+
+
+@torch.no_grad()
+def _update_param_with_optimizer(param_fn: Callable[[str, Tensor], Tensor],
+                                 optimizer_fn: Callable[[str, Tensor], Tensor], params, optimizers,
+                                 names=None) -> None:
+    """Replace every parameter by param_fn(name, p) and re-key its Adam state
+    (exp_avg / exp_avg_sq mapped through optimizer_fn, `step` kept)."""
+    names = list(params.keys()) if names is None else names
+    for name in names:
+        old = params[name]
+        new = torch.nn.Parameter(param_fn(name, old), requires_grad=old.requires_grad)
+        opt = _opt_of(optimizers, name)
+        for g in opt.param_groups:
+            for i, p in enumerate(g["params"]):
+                if p is old:
+                    st = opt.state.pop(p, {})
+                    for k in list(st.keys()):
+                        if k != "step":
+                            st[k] = optimizer_fn(k, st[k])
+                    g["params"][i] = new
+                    if st:
+                        opt.state[new] = st
+        params[name] = new
+
+
+@torch.no_grad()
+def duplicate(params, optimizers, state: Dict[str, Tensor], mask: Tensor) -> None:
+    sel = torch.where(mask)[0]
+    _update_param_with_optimizer(
+        lambda n, p: torch.cat([p, p[sel]]),
+        lambda k, v: torch.cat([v, torch.zeros((len(sel), *v.shape[1:]), device=v.device, dtype=v.dtype)]),
+        params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            state[k] = torch.cat([v, v[sel]])
+
+
+@torch.no_grad()
+def split(params, optimizers, state: Dict[str, Tensor], mask: Tensor, revised_opacity: bool = False,
+          generator: Optional[torch.Generator] = None) -> None:
+    dev = mask.device
+    sel, rest = torch.where(mask)[0], torch.where(~mask)[0]
+    scales = torch.exp(params["scales"][sel])
+    rotmats = _quat_to_rotmat(params["quats"][sel])
+    noise = torch.randn(2, len(scales), 3, device=dev, generator=generator)
+    samples = torch.einsum("nij,nj,bnj->bni", rotmats, scales, noise)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        reps = [2] + [1] * (p.dim() - 1)
+        if name == "means":
+            p_split = (p[sel] + samples).reshape(-1, 3)
+        elif name == "scales":
+            p_split = torch.log(scales / 1.6).repeat(2, 1)
+        elif name == "opacities" and revised_opacity:
+            new_o = 1.0 - torch.sqrt(1.0 - torch.sigmoid(p[sel]))
+            p_split = torch.logit(new_o).repeat(reps)
+        else:
+            p_split = p[sel].repeat(reps)
+        return torch.cat([p[rest], p_split])
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        return torch.cat([v[rest], torch.zeros((2 * len(sel), *v.shape[1:]), device=dev, dtype=v.dtype)])
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            reps = [2] + [1] * (v.dim() - 1)
+            state[k] = torch.cat([v[rest], v[sel].repeat(reps)])
+
+
+@torch.no_grad()
+def remove(params, optimizers, state: Dict[str, Tensor], mask: Tensor) -> None:
+    keep = torch.where(~mask)[0]
+    _update_param_with_optimizer(lambda n, p: p[keep], lambda k, v: v[keep], params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            state[k] = v[keep]
+
+
+@torch.no_grad()
+def reset_opa(params, optimizers, state: Dict[str, Tensor], value: float) -> None:
+    _update_param_with_optimizer(
+        lambda n, p: torch.clamp(p, max=math.log(value / (1.0 - value))),
+        lambda k, v: torch.zeros_like(v), params, optimizers, names=["opacities"])
+
+
+@dataclass
+class DefaultStrategy:
+    prune_opa: float = 0.005
+    grow_grad2d: float = 0.0002
+    grow_scale3d: float = 0.01
+    grow_scale2d: float = 0.05
+    prune_scale3d: float = 0.1
+    prune_scale2d: float = 0.15
+    refine_scale2d_stop_iter: int = 0
+    refine_start_iter: int = 500
+    refine_stop_iter: int = 15_000
+    reset_every: int = 3000
+    refine_every: int = 100
+    pause_refine_after_reset: int = 0
+    absgrad: bool = False
+    revised_opacity: bool = False
+    verbose: bool = False
+    key_for_gradient: str = "means2d"
+    seed: int = 42                      # shared by all replicas (see module docstring)
+
+    def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
+        return {"grad2d": None, "count": None, "scene_scale": scene_scale, "radii": None,
+                "generator": None}
+
+    def check_sanity(self, params, optimizers) -> None:
+        for key in ("means", "scales", "quats", "opacities"):
+            assert key in params, f"{key} is required in params"
+        assert set(params.keys()) <= set(optimizers.keys()), "every parameter needs an optimizer"
+
+    def step_pre_backward(self, params, optimizers, state, step: int, info: Dict[str, Any]) -> None:
+        assert self.key_for_gradient in info, "The 2D means of the Gaussians is required but missing."
+        info[self.key_for_gradient].retain_grad()
+
+    def step_post_backward(self, params, optimizers, state, step: int, info: Dict[str, Any],
+                           packed: bool = False) -> None:
+        if step >= self.refine_stop_iter:
+            return
+        self._update_state(params, state, info, packed=packed)
+        if (step > self.refine_start_iter and step % self.refine_every == 0
+                and step % self.reset_every >= self.pause_refine_after_reset):
+            self._sync_state(state)
+            n_dupli, n_split = self._grow_gs(params, optimizers, state, step)
+            n_prune = self._prune_gs(params, optimizers, state, step)
+            if self.verbose:
+                print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split, {n_prune} GSs "
+                      f"pruned. Now having {len(params['means'])} GSs.")
+            state["grad2d"].zero_()
+            state["count"].zero_()
+            if state["radii"] is not None:
+                state["radii"].zero_()
+        if step % self.reset_every == 0 and step > 0:
+            reset_opa(params, optimizers, state, value=self.prune_opa * 2.0)
+
+    # ------------------------------------------------------------------ internals
+    def _update_state(self, params, state, info, packed: bool = False) -> None:
+        for key in ("width", "height", "n_cameras", "radii", self.key_for_gradient):
+            assert key in info, f"{key} is required but missing."
+        m2d = info[self.key_for_gradient]
+        grads = (m2d.absgrad if self.absgrad else m2d.grad).clone()
+        grads[..., 0] *= info["width"] / 2.0 * info["n_cameras"]
+        grads[..., 1] *= info["height"] / 2.0 * info["n_cameras"]
+        n = len(params["means"])
+        dev = grads.device
+        if state["grad2d"] is None:
+            state["grad2d"] = torch.zeros(n, device=dev)
+            state["count"] = torch.zeros(n, device=dev)
+        if self.refine_scale2d_stop_iter > 0 and state["radii"] is None:
+            state["radii"] = torch.zeros(n, device=dev)
+        radii = info["radii"]
+        sel = (radii > 0).all(dim=-1)                       # [C,N]
+        gs_ids = torch.where(sel)[1]
+        g = grads[sel]
+        state["grad2d"].index_add_(0, gs_ids, g.norm(dim=-1))
+        state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
+        if self.refine_scale2d_stop_iter > 0:
+            r = radii[sel].max(dim=-1).values.float() / float(max(info["width"], info["height"]))
+            state["radii"][gs_ids] = torch.maximum(state["radii"][gs_ids], r)
+
+    def _sync_state(self, state) -> None:
+        """Replicas: sum the statistics over ranks so every rank decides identically."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(state["grad2d"])
+            dist.all_reduce(state["count"])
+            if state["radii"] is not None:
+                dist.all_reduce(state["radii"], op=dist.ReduceOp.MAX)
+
+    def _generator(self, state, device) -> torch.Generator:
+        if state.get("generator") is None:
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed)
+            state["generator"] = g
+        return state["generator"]
+
+    def _grow_gs(self, params, optimizers, state, step: int):
+        count = state["count"]
+        grads = state["grad2d"] / count.clamp_min(1)
+        dev = grads.device
+        is_grad_high = grads > self.grow_grad2d
+        is_small = torch.exp(params["scales"]).max(dim=-1).values <= self.grow_scale3d * state["scene_scale"]
+        is_dupli = is_grad_high & is_small
+        n_dupli = int(is_dupli.sum().item())
+        is_large = ~is_small
+        is_split = is_grad_high & is_large
+        if step < self.refine_scale2d_stop_iter:
+            is_split |= state["radii"] > self.grow_scale2d
+        n_split = int(is_split.sum().item())
+        if n_dupli > 0:
+            duplicate(params, optimizers, state, is_dupli)
+        is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=dev)])
+        if n_split > 0:
+            split(params, optimizers, state, is_split, self.revised_opacity,
+                  generator=self._generator(state, dev))
+        return n_dupli, n_split
+
+    def _prune_gs(self, params, optimizers, state, step: int) -> int:
+        is_prune = torch.sigmoid(params["opacities"].flatten()) < self.prune_opa
+        if step > self.reset_every:
+            is_too_big = torch.exp(params["scales"]).max(dim=-1).values > self.prune_scale3d * state["scene_scale"]
+            if step < self.refine_scale2d_stop_iter:
+                is_too_big |= state["radii"] > self.prune_scale2d
+            is_prune = is_prune | is_too_big
+        n_prune = int(is_prune.sum().item())
+        if n_prune > 0:
+            remove(params, optimizers, state, is_prune)
+        return n_prune

@@ -112,3 +112,51 @@ def test_grad_arena_hands_out_views_and_matches_plain_grads():
         assert all(sync.arena.owns(k, p.grad) for k, p in splats.items())
     finally:
         R.set_grad_arena(None)
+
+
+def test_end_to_end_training_with_strategy_reduces_loss():
+    """A8 + F1 + F2 together: render -> L1+SSIM -> backward -> densify -> fused Adam.
+    Fit a small scene to images of a ground-truth scene; the loss must fall and
+    densification must change the Gaussian count without breaking optimizer state."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
+    S = importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+    torch.manual_seed(0)
+    W, H = 128, 96
+    gt = scenes.make_scene(1500, 7, box=(1.0, 0.7, 0.4), scale_mean=0.04)
+    vms, Ks = scenes.cameras(range(0, 100, 10), width=W, height=H, f=110.0, dist=2.5)
+    c2ws, Ks = torch.linalg.inv(vms).cuda(), Ks.cuda()
+    gt_splats, _ = runner.create_splats_with_optimizers(
+        gt["means"], torch.rand(1500, 3), torch.log(gt["scales"]), quats=gt["quats"],
+        opacities_logit=torch.logit(gt["opacities"]), shN=gt["shN"])
+    with torch.no_grad():
+        gt_splats["sh0"].copy_(gt["sh0"].cuda())
+        targets = [runner.rasterize_splats(gt_splats, c2ws[i:i + 1], Ks[i:i + 1], W, H, sh_degree=3)[0]
+                   .clamp(0, 1).detach() for i in range(10)]
+    # learner: perturbed, fewer Gaussians
+    n0 = 800
+    pts = gt["means"][:n0] + 0.02 * torch.randn(n0, 3)
+    knn = importlib.import_module("3dgs_monocular_depth_init_amd.knn")
+    scales0 = knn.initial_log_scales(pts.cuda()).cpu()
+    splats, opts = runner.create_splats_with_optimizers(pts, torch.rand(n0, 3), scales0, init_opacity=0.3)
+    fused = optim.FusedAdam(opts)
+    strat = S.DefaultStrategy(refine_start_iter=20, refine_every=20, reset_every=10_000,
+                              refine_stop_iter=200, grow_grad2d=5e-5)
+    strat.check_sanity(splats, fused)
+    st = strat.initialize_state(scene_scale=1.0)
+    losses, counts = [], []
+    for step in range(121):
+        i = step % 10
+        loss, info = runner.train_step(splats, fused, c2ws[i:i + 1], Ks[i:i + 1], targets[i], step=3000 + step,
+                                       ssim_lambda=0.2, strategy=None, strategy_state=None) if False else \
+            runner.train_step(splats, fused, c2ws[i:i + 1], Ks[i:i + 1], targets[i], step=step,
+                              ssim_lambda=0.2, strategy=strat, strategy_state=st)
+        losses.append(float(loss))
+        counts.append(len(splats["means"]))
+    assert all(math.isfinite(x) for x in losses)
+    assert sum(losses[-10:]) / 10 < 0.8 * sum(losses[:10]) / 10, (losses[:10], losses[-10:])
+    assert counts[-1] != counts[0], "densification never changed the Gaussian count"
+    for k, p in splats.items():
+        stt = opts[k].state[p]
+        assert stt["exp_avg"].shape == p.shape
