@@ -36,6 +36,8 @@ SIGNATURES = {
 }
 SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_ssim_l1_bwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
+SIGNATURES["gsr_l1_fwd"] = [_i64, _p, _p, _p, _p]
+SIGNATURES["gsr_l1_bwd"] = [_i64, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_debug_tree_reduce8"] = [_p, _p, _p, _p]
 SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p]
 SIGNATURES["gsr_adam_step"] = [_i, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]

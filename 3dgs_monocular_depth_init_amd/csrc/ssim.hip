@@ -196,7 +196,71 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
   }
 }
 
+// Plain L1 (runner.py:506 with ssim_lambda = 0): contiguous buffers, 16 B per lane.
+__global__ void __launch_bounds__(256)
+l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
+              double *__restrict__ sum) {
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 x = *reinterpret_cast<const float4 *>(a + i);
+      const float4 y = *reinterpret_cast<const float4 *>(b + i);
+      acc += (double)(fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w));
+    } else {
+      for (int64_t k = i; k < n; ++k) acc += (double)fabsf(a[k] - b[k]);
+    }
+  }
+  __shared__ double red[4];
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256)
+l1_bwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
+              const float *__restrict__ weight, float *__restrict__ grad) {
+  const float w = weight[0];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  auto sg = [w](float d) { return d > 0.f ? w : (d < 0.f ? -w : 0.f); };
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 x = *reinterpret_cast<const float4 *>(a + i);
+      const float4 y = *reinterpret_cast<const float4 *>(b + i);
+      *reinterpret_cast<float4 *>(grad + i) =
+          make_float4(sg(x.x - y.x), sg(x.y - y.y), sg(x.z - y.z), sg(x.w - y.w));
+    } else {
+      for (int64_t k = i; k < n; ++k) grad[k] = sg(a[k] - b[k]);
+    }
+  }
+}
+
 }  // namespace gsr
+
+extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *sum, void *stream) {
+  GSR_REQUIRE(n >= 0 && a && b && sum, "l1_fwd: bad arguments");
+  GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "l1_fwd: buffers must be 16-byte aligned");
+  GSR_CHECK_HIP(hipMemsetAsync(sum, 0, sizeof(double), (hipStream_t)stream));
+  if (n == 0) return GSR_OK;
+  int blocks = (int)(gsr::ceil_div64(n, 1024) < 2048 ? gsr::ceil_div64(n, 1024) : 2048);
+  hipLaunchKernelGGL(gsr::l1_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
+                     sum);
+  GSR_CHECK_LAUNCH("l1_fwd");
+  return GSR_OK;
+}
+
+extern "C" int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *weight,
+                          float *grad, void *stream) {
+  GSR_REQUIRE(n >= 0 && a && b && weight && grad, "l1_bwd: bad arguments");
+  GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad) % 16 == 0,
+              "l1_bwd: buffers must be 16-byte aligned");
+  if (n == 0) return GSR_OK;
+  int blocks = (int)(gsr::ceil_div64(n, 1024) < 2048 ? gsr::ceil_div64(n, 1024) : 2048);
+  hipLaunchKernelGGL(gsr::l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
+                     weight, grad);
+  GSR_CHECK_LAUNCH("l1_bwd");
+  return GSR_OK;
+}
 
 // img strides are in ELEMENTS for a logical [N, CH, H, W] image (pass the
 // strides of an NHWC tensor permuted to NCHW to consume it in place).

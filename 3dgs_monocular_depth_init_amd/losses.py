@@ -65,6 +65,34 @@ class _SsimL1(torch.autograd.Function):
         return grad, None, None, None
 
 
+class _L1(torch.autograd.Function):
+    """mean |a - b| over contiguous buffers: one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        s = torch.empty(1, dtype=torch.float64, device=a.device)
+        call("gsr_l1_fwd", a.numel(), ptr(a), ptr(b), ptr(s), _st())
+        ctx.save_for_backward(a, b)
+        return (s[0] / a.numel()).float()
+
+    @staticmethod
+    def backward(ctx, v):
+        a, b = ctx.saved_tensors
+        w = (v / a.numel()).float().reshape(1).contiguous()
+        grad = torch.empty_like(a)
+        call("gsr_l1_bwd", a.numel(), ptr(a), ptr(b), ptr(w), ptr(grad), _st())
+        return grad, None
+
+
+def l1_loss(colors: Tensor, pixels: Tensor) -> Tensor:
+    """F.l1_loss(colors, pixels) (runner.py:506) in two launches."""
+    if not (colors.is_cuda and pixels.is_cuda):
+        from ._lib import GsrastError
+        raise GsrastError("l1_loss: tensors must be on a ROCm device; there is no CPU path")
+    assert colors.shape == pixels.shape
+    return _L1.apply(colors.contiguous().float(), pixels.detach().contiguous().float())
+
+
 def _check(img1: Tensor, img2: Tensor):
     if not (img1.is_cuda and img2.is_cuda):
         from ._lib import GsrastError

@@ -163,7 +163,8 @@ def train_step(
         from .losses import l1_ssim_loss                                 # runner.py:506-510 fused
         loss = l1_ssim_loss(colors, pixels, ssim_lambda)
     else:
-        loss = torch.nn.functional.l1_loss(colors, pixels)              # runner.py:506
+        from .losses import l1_loss
+        loss = l1_loss(colors, pixels)                                  # runner.py:506
     loss.backward()                                                      # runner.py:547
     if grad_sync is not None:
         grad_sync()

@@ -188,6 +188,12 @@ int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1, const int64_
                     const float *dm_s1, const float *dm_s12, const float *weights, float *grad,
                     const int64_t *stridesg, void *stream);
 
+/* Plain L1 over n contiguous floats (16-byte aligned): sum |a-b| into a device
+ * fp64 (zeroed inside); grad = weight[0] * sign(a-b), weight a device float. */
+int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *sum, void *stream);
+int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *weight, float *grad,
+               void *stream);
+
 /* Test hook: in [8][64] -> out[0..63] = per-lane result of the 8-value lane-swap
  * reduction tree used by gsr_rasterize_bwd, out[64..127] = wave sum of in[0],
  * idx_out[64] = which input each lane holds the total of. */
