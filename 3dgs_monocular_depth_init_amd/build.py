@@ -22,7 +22,7 @@ ARCH = "gfx950"
 SOURCES = ["api.hip", "project.hip", "isect.hip", "raster_fwd.hip", "raster_bwd.hip",
            "init_depth.hip", "train_ops.hip", "ssim.hip", "knn.hip"]
 FLAGS = ["-O3", "-std=c++17", "-shared", "-fPIC", f"--offload-arch={ARCH}",
-         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

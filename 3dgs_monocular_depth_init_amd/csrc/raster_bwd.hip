@@ -8,6 +8,8 @@
 // as [64][16] rows; each row is then flushed with ONE 64-byte-aligned group
 // of float atomics into grad_rows[g][16] (16 adjacent lanes = one memory-side
 // atomic request), instead of 9-11 scattered dword atomics per Gaussian.
+#include <type_traits>
+
 #include "raster_common.h"
 
 namespace gsr {
@@ -22,7 +24,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 template <int CH, bool ABSGRAD>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (CH <= 3 && !ABSGRAD) ? 5 : 4)
 raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   const float *__restrict__ conics, const float *__restrict__ colors,
                   int color_stride, const float *__restrict__ opacities, int opac_per_camera,
@@ -33,10 +35,13 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
                   const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows) {
-  __shared__ float4 sA[2][64];
-  __shared__ float4 sB[2][64];
-  __shared__ float4 sC[2][64];
-  __shared__ int sId[2][64];
+  __shared__ float4 sA[1][64];   // single buffer: the batch-end barriers already order reuse
+  __shared__ float4 sB[1][64];
+  // CH <= 3: {col2, quadrant mask}; CH 4,5: {col2, col3, col4, mask} (LDS per wave
+  // decides how many waves fit a CU: 9.7 KB -> 16 waves)
+  using CT = typename std::conditional<(CH <= 3), float2, float4>::type;
+  __shared__ CT sC[1][64];
+  __shared__ int sId[1][64];
   __shared__ __attribute__((aligned(16))) float sG[64][GSR_GRAD_ROW];  // batch gradient rows
 
   if ((int)blockIdx.x >= n_tiles) return;
@@ -107,13 +112,14 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
                     (float)tx0, (float)ty0, rec);
   }
 
-  int buf = 0;
+  constexpr int buf = 0;
   for (int batch_end = start; batch_end >= s; batch_end -= 64) {
     const int n = min(64, batch_end - s + 1);
     if (lane < n) {
       sA[buf][lane] = rec.a;
       sB[buf][lane] = rec.b;
-      sC[buf][lane] = rec.c;
+      if constexpr (CH <= 3) sC[buf][lane] = make_float2(rec.c.x, rec.c.w);
+      else sC[buf][lane] = rec.c;
       sId[buf][lane] = rId;
     }
     sG[lane][15] = 0.f;   // "row touched" flag of Gaussian `lane` of this batch
@@ -126,7 +132,14 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
     }
 
     for (int j = 0; j < n; ++j) {
-      const float4 Ac = sA[buf][j], Bc = sB[buf][j], Cc = sC[buf][j];
+      const float4 Ac = sA[buf][j], Bc = sB[buf][j];
+      float4 Cc;
+      if constexpr (CH <= 3) {
+        const float2 c2 = sC[buf][j];
+        Cc = make_float4(c2.x, 0.f, 0.f, c2.y);
+      } else {
+        Cc = sC[buf][j];
+      }
       const int idx = batch_end - j;
       unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(Cc.w));
 #pragma unroll
@@ -241,7 +254,6 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
       }
     }
     __syncthreads();
-    buf ^= 1;
   }
 }
 
