@@ -1,0 +1,37 @@
+"""Digest gpurun_out/<tag>_* (written by tools/profile_round.sh) into profiles/:
+kernel stats CSV, per-kernel PMC means (JSON) and profiles/pmc_traffic.json
+(HBM bytes per launch of each gsr kernel, gfx950 correction applied: FETCH_SIZE is
+reported in KiB and counts half of the bytes of wide coalesced reads ->
+traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024; MI355X_MICROARCH.md section HBM)."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+st = glob.glob(f"gpurun_out/{tag}_stats/*/*_kernel_stats.csv")
+if st:
+    shutil.copy(st[0], f"profiles/{tag}_kernel_stats.csv")
+pmc = {}
+for d in glob.glob(f"gpurun_out/{tag}_pmc_*/"):
+    for f in glob.glob(d + "*/*_counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            if "gsr" in k:
+                pmc.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
+json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
+traffic = {}
+names = {"raster_bwd_kernel": "gsr_rasterize_bwd", "raster_fwd_kernel": "gsr_rasterize_fwd",
+         "project_fwd_kernel": "gsr_project_fwd", "project_bwd_kernel": "gsr_project_bwd",
+         "isect_emit_kernel": "gsr_isect_emit", "tile_sort_small_kernel": "gsr_tile_sort",
+         "adam_kernel": "gsr_adam_step"}
+for k, cs in pmc.items():
+    for frag, entry in names.items():
+        if frag in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic[entry] = int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
+json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1))
