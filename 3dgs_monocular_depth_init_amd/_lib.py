@@ -22,17 +22,16 @@ _i64 = C.c_int64
 # name -> argtypes; every function returns int except the three below.
 SIGNATURES = {
     "gsr_project_fwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i,
-                        _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _p],
+                        _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p, _p, _p],
     "gsr_project_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p, _p, _p,
                         _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p],
     "gsr_isect_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p],
     "gsr_isect_scan": [_i, _p, _p, _p, _p],
     "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
     "gsr_tile_sort": [_i, _p, _p, _p, _p, _p, _p],
-    "gsr_rasterize_fwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
-                          _p, _p, _p],
-    "gsr_rasterize_bwd": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p,
-                          _p, _p, _p, _i, _p, _p],
+    "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
+    "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gsr_rasterize_bwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
 }
 SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_ssim_l1_bwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]

@@ -25,7 +25,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    float *__restrict__ conics, float *__restrict__ compensations,
                    float *__restrict__ colors_out, int color_stride, int depth_channel,
                    int activations, float *__restrict__ opacities_out, int tile_w, int tile_h,
-                   int32_t *__restrict__ tile_counts) {
+                   int32_t *__restrict__ tile_counts, float *__restrict__ records) {
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
   int c = (int)(g / N);
@@ -89,6 +89,15 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     co[2] = fmaxf(b + 0.5f, 0.f);
   }
   if (depth_channel >= 0) co[depth_channel] = p.depth;
+  if (records && p.rx > 0) {   // packed compositing record (see raster_common.h)
+    float cc5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < color_stride && k < 5; ++k) cc5[k] = co[k];
+    const float op_eff = calc_comp ? opac * p.comp : opac;
+    float4 *row = reinterpret_cast<float4 *>(records + g * 16);
+    row[0] = make_float4(p.mx, p.my, p.ca, p.cb);
+    row[1] = make_float4(p.cc, op_eff, cc5[0], cc5[1]);
+    row[2] = make_float4(cc5[2], cc5[3], cc5[4], 0.f);
+  }
 }
 
 // One thread per Gaussian; loops over cameras.
@@ -228,7 +237,7 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
                                float *conics, float *compensations, float *colors_out,
                                int color_stride, int depth_channel, int activations,
                                float *opacities_out, int tile_w, int tile_h,
-                               int32_t *tile_counts, void *stream) {
+                               int32_t *tile_counts, float *records, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "project_fwd: bad sizes C=%d N=%d %dx%d",
               C, N, width, height);
   if ((int64_t)C * N == 0) return GSR_OK;
@@ -240,6 +249,7 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
                 "project_fwd: SH requested without sh0/shN/campos/colors_out");
     GSR_REQUIRE(color_stride >= 3, "project_fwd: color_stride %d < 3", color_stride);
   }
+  GSR_REQUIRE(!records || (colors_out && opacities), "project_fwd: records need colours and opacities");
   if (colors_out)
     GSR_REQUIRE(depth_channel < color_stride, "project_fwd: depth_channel %d >= stride %d",
                 depth_channel, color_stride);
@@ -258,7 +268,7 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
                      near_plane, far_plane, radius_clip, calc_compensations, sh_degree, sh0,
                      sh0_stride, shN, shN_stride, radii, means2d, depths, conics, compensations,
                      colors_out, color_stride, colors_out ? depth_channel : -1, activations,
-                     opacities_out, tile_w, tile_h, tile_counts);
+                     opacities_out, tile_w, tile_h, tile_counts, records);
   GSR_CHECK_LAUNCH("project_fwd");
   return GSR_OK;
 }

@@ -25,9 +25,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 
 template <int CH, bool ABSGRAD>
 __global__ void __launch_bounds__(64, (CH <= 3 && !ABSGRAD) ? 5 : 4)
-raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
-                  const float *__restrict__ conics, const float *__restrict__ colors,
-                  int color_stride, const float *__restrict__ opacities, int opac_per_camera,
+raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ tile_order,
@@ -108,8 +106,7 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   int rId = 0;
   if (start - lane >= s) {
     rId = flatten_ids[start - lane];
-    stage_gauss<CH>(rId, N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
-                    (float)tx0, (float)ty0, rec);
+    stage_gauss<CH>(rId, records, (float)tx0, (float)ty0, rec);
   }
 
   constexpr int buf = 0;
@@ -127,8 +124,7 @@ raster_bwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
     const int nb = batch_end - 64;
     if (nb - lane >= s) {
       rId = flatten_ids[nb - lane];
-      stage_gauss<CH>(rId, N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
-                      (float)tx0, (float)ty0, rec);
+      stage_gauss<CH>(rId, records, (float)tx0, (float)ty0, rec);
     }
 
     for (int j = 0; j < n; ++j) {
@@ -271,26 +267,22 @@ __global__ void debug_tree_reduce8_kernel(const float *__restrict__ in, float *_
 }
 
 template <int CH>
-static int launch_bwd(int n_tiles, int N, const float *means2d, const float *conics,
-                      const float *colors, int color_stride, const float *opacities,
-                      int opac_per_camera, const float *backgrounds, int width, int height,
-                      int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
-                      const int32_t *last_ids, const float *v_render_colors,
-                      const float *v_render_alphas, int absgrad, float *grad_rows,
-                      hipStream_t stream) {
+static int launch_bwd(int n_tiles, const float *records, const float *backgrounds, int width,
+                      int height, int tile_w, int tile_h, const int32_t *tile_offsets,
+                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      const float *render_alphas, const int32_t *last_ids,
+                      const float *v_render_colors, const float *v_render_alphas, int absgrad,
+                      float *grad_rows, hipStream_t stream) {
   if (absgrad)
-    hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), 0, stream,
-                       n_tiles, N, means2d, conics, colors, color_stride, opacities,
-                       opac_per_camera, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
-                       grad_rows);
+    hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), 0, stream, n_tiles,
+                       records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
+                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors,
+                       v_render_alphas, grad_rows);
   else
-    hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(n_tiles), dim3(64), 0, stream,
-                       n_tiles, N, means2d, conics, colors, color_stride, opacities,
-                       opac_per_camera, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas,
-                       grad_rows);
+    hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(n_tiles), dim3(64), 0, stream, n_tiles,
+                       records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
+                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors,
+                       v_render_alphas, grad_rows);
   GSR_CHECK_LAUNCH("rasterize_bwd");
   return GSR_OK;
 }
@@ -306,30 +298,27 @@ extern "C" int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_
   return GSR_OK;
 }
 
-extern "C" int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *conics,
-                                 const float *colors, int color_stride, const float *opacities,
-                                 int opac_per_camera, const float *backgrounds, int width,
-                                 int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                                 const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
+extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds,
+                                 int width, int height, int tile_w, int tile_h,
+                                 const int32_t *tile_offsets, const int32_t *tile_order,
+                                 const int32_t *flatten_ids, const float *render_alphas,
                                  const int32_t *last_ids, const float *v_render_colors,
                                  const float *v_render_alphas, int absgrad, float *grad_rows,
                                  void *stream) {
-  GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "rasterize_bwd: bad sizes");
+  GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_bwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
               "rasterize_bwd: tile grid does not match image");
-  GSR_REQUIRE(CH >= 1 && CH <= 5 && color_stride >= CH, "rasterize_bwd: CH=%d stride=%d", CH,
-              color_stride);
-  if (C == 0 || N == 0) return GSR_OK;
-  GSR_REQUIRE(means2d && conics && colors && opacities && tile_offsets &&
-                  render_alphas && last_ids && v_render_colors && v_render_alphas && grad_rows,
+  GSR_REQUIRE(CH >= 1 && CH <= 5, "rasterize_bwd: CH=%d", CH);
+  if (C == 0) return GSR_OK;
+  GSR_REQUIRE(tile_offsets && render_alphas && last_ids && v_render_colors && v_render_alphas &&
+                  grad_rows,
               "rasterize_bwd: null pointer");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;
-#define GSR_BWD_CASE(K)                                                                       \
-  case K:                                                                                     \
-    return gsr::launch_bwd<K>(n_tiles, N, means2d, conics, colors, color_stride, opacities,   \
-                              opac_per_camera, backgrounds, width, height, tile_w, tile_h,    \
-                              tile_offsets, tile_order, flatten_ids, render_alphas, last_ids, \
+#define GSR_BWD_CASE(K)                                                                         \
+  case K:                                                                                       \
+    return gsr::launch_bwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
+                              tile_offsets, tile_order, flatten_ids, render_alphas, last_ids,   \
                               v_render_colors, v_render_alphas, absgrad, grad_rows, st);
   switch (CH) {
     GSR_BWD_CASE(1)

@@ -47,19 +47,21 @@ __device__ __forceinline__ float min_sigma_rect(float a, float b, float c, float
   return m;
 }
 
-// Gather Gaussian g and build its LDS record for the tile at pixel origin (tx0, ty0).
+// Packed per-(camera,Gaussian) compositing record, one 64-byte row (= one cache
+// line / one fabric request per gather instead of four scattered arrays):
+//   [0] mx  my  conic.a conic.b   [1] conic.c opacity col0 col1   [2] col2 col3 col4 -
+// written by gsr_project_fwd (or gsr_pack_records for caller-supplied colours).
+constexpr int REC_FLOATS = 16;
+
+// Gather Gaussian g's record and build its LDS image for the tile at (tx0, ty0).
 template <int CH>
-__device__ __forceinline__ void stage_gauss(int g, int N, const float *__restrict__ means2d,
-                                            const float *__restrict__ conics,
-                                            const float *__restrict__ colors, int color_stride,
-                                            const float *__restrict__ opacities,
-                                            int opac_per_camera, float tx0, float ty0,
-                                            TileRec<CH> &r) {
-  const float2 m = *reinterpret_cast<const float2 *>(means2d + (int64_t)g * 2);
-  const float *cn = conics + (int64_t)g * 3;
-  const float *cl = colors + (int64_t)g * color_stride;
-  const float op = opacities[opac_per_camera ? g : (g % N)];
-  const float a = cn[0], b = cn[1], c = cn[2];
+__device__ __forceinline__ void stage_gauss(int g, const float *__restrict__ records, float tx0,
+                                            float ty0, TileRec<CH> &r) {
+  const float4 *row = reinterpret_cast<const float4 *>(records + (int64_t)g * REC_FLOATS);
+  const float4 r0 = row[0], r1 = row[1];
+  float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (CH > 2) r2 = row[2];
+  const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
   // alpha >= 1/255  <=>  sigma <= ln(255*op); small margin keeps the test conservative
   const float tau = logf(op * 255.0f);
   const float tau_m = tau + 1e-4f * (1.0f + fabsf(tau));
@@ -67,13 +69,12 @@ __device__ __forceinline__ void stage_gauss(int g, int N, const float *__restric
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float x0 = tx0 + 8.f * (float)(q & 1) + 0.5f, y0 = ty0 + 8.f * (float)(q >> 1) + 0.5f;
-    const float ms = min_sigma_rect(a, b, c, m.x, m.y, x0, x0 + 7.f, y0, y0 + 7.f);
+    const float ms = min_sigma_rect(a, b, c, r0.x, r0.y, x0, x0 + 7.f, y0, y0 + 7.f);
     qmask |= (ms <= tau_m) ? (1 << q) : 0;
   }
-  r.a = make_float4(m.x, m.y, 0.5f * a * LOG2E, b * LOG2E);
-  r.b = make_float4(0.5f * c * LOG2E, op, cl[0], (CH > 1) ? cl[1] : 0.f);
-  r.c = make_float4((CH > 2) ? cl[2] : 0.f, (CH > 3) ? cl[3] : 0.f, (CH > 4) ? cl[4] : 0.f,
-                    __int_as_float(qmask));
+  r.a = make_float4(r0.x, r0.y, 0.5f * a * LOG2E, b * LOG2E);
+  r.b = make_float4(0.5f * c * LOG2E, op, r1.z, r1.w);
+  r.c = make_float4(r2.x, r2.y, r2.z, __int_as_float(qmask));
 }
 
 }  // namespace gsr

@@ -15,9 +15,7 @@ namespace gsr {
 
 template <int CH>
 __global__ void __launch_bounds__(64, (CH <= 3) ? 8 : 6)
-raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
-                  const float *__restrict__ conics, const float *__restrict__ colors,
-                  int color_stride, const float *__restrict__ opacities, int opac_per_camera,
+raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ tile_order,
@@ -63,8 +61,7 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
   TileRec<CH> rec;
   if (s + lane < e)
-    stage_gauss<CH>(flatten_ids[s + lane], N, means2d, conics, colors, color_stride, opacities,
-                    opac_per_camera, (float)tx0, (float)ty0, rec);
+    stage_gauss<CH>(flatten_ids[s + lane], records, (float)tx0, (float)ty0, rec);
   int buf = 0;
   unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
   for (int base = s; base < e; base += 64) {
@@ -83,8 +80,7 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
     __syncthreads();
     const int nb = base + 64;
     if (nb + lane < e)
-      stage_gauss<CH>(flatten_ids[nb + lane], N, means2d, conics, colors, color_stride,
-                      opacities, opac_per_camera, (float)tx0, (float)ty0, rec);
+      stage_gauss<CH>(flatten_ids[nb + lane], records, (float)tx0, (float)ty0, rec);
     for (int j = 0; j < n; ++j) {
       const float4 Ac = sA[buf][j], Bc = sB[buf][j];
       float4 Cc;
@@ -145,48 +141,71 @@ raster_fwd_kernel(int n_tiles, int N, const float *__restrict__ means2d,
 }
 
 template <int CH>
-static int launch_fwd(int n_tiles, int N, const float *means2d, const float *conics,
-                      const float *colors, int color_stride, const float *opacities,
-                      int opac_per_camera, const float *backgrounds, int width, int height,
-                      int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors, float *render_alphas,
-                      int32_t *last_ids, hipStream_t stream) {
-  hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), 0, stream, n_tiles,
-                     N, means2d, conics, colors, color_stride, opacities, opac_per_camera,
-                     backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order, flatten_ids,
-                     render_colors, render_alphas, last_ids);
+static int launch_fwd(int n_tiles, const float *records, const float *backgrounds, int width,
+                      int height, int tile_w, int tile_h, const int32_t *tile_offsets,
+                      const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors,
+                      float *render_alphas, int32_t *last_ids, hipStream_t stream) {
+  hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), 0, stream, n_tiles, records,
+                     backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                     flatten_ids, render_colors, render_alphas, last_ids);
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
 }
 
+// Pack caller-supplied per-pair arrays into compositing records (the projection
+// kernel writes the records itself on the SH path).
+__global__ void __launch_bounds__(256)
+pack_records_kernel(int64_t total, int N, int CH, const float *__restrict__ means2d,
+                    const float *__restrict__ conics, const float *__restrict__ colors,
+                    int color_stride, const float *__restrict__ opacities, int opac_per_camera,
+                    float *__restrict__ records) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const float *cl = colors + g * color_stride;
+  float c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < CH; ++k) c[k] = cl[k];
+  float4 *row = reinterpret_cast<float4 *>(records + g * REC_FLOATS);
+  row[0] = make_float4(means2d[g * 2], means2d[g * 2 + 1], conics[g * 3], conics[g * 3 + 1]);
+  row[1] = make_float4(conics[g * 3 + 2], opacities[opac_per_camera ? g : (g % N)], c[0], c[1]);
+  row[2] = make_float4(c[2], c[3], c[4], 0.f);
+}
+
 }  // namespace gsr
 
-extern "C" int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, const float *conics,
-                                 const float *colors, int color_stride, const float *opacities,
-                                 int opac_per_camera, const float *backgrounds, int width,
-                                 int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                                 const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors,
+extern "C" int gsr_pack_records(int C, int N, int CH, const float *means2d, const float *conics,
+                                const float *colors, int color_stride, const float *opacities,
+                                int opac_per_camera, float *records, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && CH >= 1 && CH <= 5 && color_stride >= CH, "pack_records: bad sizes");
+  const int64_t total = (int64_t)C * N;
+  if (total == 0) return GSR_OK;
+  GSR_REQUIRE(means2d && conics && colors && opacities && records, "pack_records: null pointer");
+  hipLaunchKernelGGL(gsr::pack_records_kernel, dim3((unsigned)gsr::ceil_div64(total, 256)),
+                     dim3(256), 0, (hipStream_t)stream, total, N, CH, means2d, conics, colors,
+                     color_stride, opacities, opac_per_camera, records);
+  GSR_CHECK_LAUNCH("pack_records");
+  return GSR_OK;
+}
+
+extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds,
+                                 int width, int height, int tile_w, int tile_h,
+                                 const int32_t *tile_offsets, const int32_t *tile_order,
+                                 const int32_t *flatten_ids, float *render_colors,
                                  float *render_alphas, int32_t *last_ids, void *stream) {
-  GSR_REQUIRE(C >= 0 && N >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
+  GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
               "rasterize_fwd: tile grid %dx%d does not match %dx%d image", tile_w, tile_h, width,
               height);
-  GSR_REQUIRE(CH >= 1 && CH <= 5 && color_stride >= CH, "rasterize_fwd: CH=%d stride=%d", CH,
-              color_stride);
+  GSR_REQUIRE(CH >= 1 && CH <= 5, "rasterize_fwd: CH=%d", CH);
   if (C == 0) return GSR_OK;
   GSR_REQUIRE(tile_offsets && render_colors && render_alphas && last_ids,
               "rasterize_fwd: null pointer");
-  GSR_REQUIRE(N == 0 || (means2d && conics && colors && opacities),
-              "rasterize_fwd: null Gaussian arrays");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;
-#define GSR_FWD_CASE(K)                                                                      \
-  case K:                                                                                    \
-    return gsr::launch_fwd<K>(n_tiles, N, means2d, conics, colors, color_stride, opacities,  \
-                              opac_per_camera, backgrounds, width, height, tile_w, tile_h,   \
-                              tile_offsets, tile_order, flatten_ids, render_colors,          \
-                              render_alphas,                                                  \
-                              last_ids, st);
+#define GSR_FWD_CASE(K)                                                                         \
+  case K:                                                                                       \
+    return gsr::launch_fwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
+                              tile_offsets, tile_order, flatten_ids, render_colors,             \
+                              render_alphas, last_ids, st);
   switch (CH) {
     GSR_FWD_CASE(1)
     GSR_FWD_CASE(2)

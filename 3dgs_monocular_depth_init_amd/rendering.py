@@ -136,6 +136,8 @@ class _ProjectSH(torch.autograd.Function):
                     if activations & ACT_SIGMOID_OPAC else None)
         tile_counts = (torch.empty(C * tile_w * tile_h, dtype=torch.int32, device=dev)
                        if tile_w > 0 else None)
+        records = (torch.empty(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
+                   if sh_degree >= 0 and opacities is not None else None)
         radii = torch.empty(C, N, 2, dtype=torch.int32, device=dev)
         means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
         depths = torch.empty(C, N, dtype=torch.float32, device=dev)
@@ -161,7 +163,7 @@ class _ProjectSH(torch.autograd.Function):
              int(calc_comp), sh_degree, sh0_ptr, sh0_stride, shN_ptr, shN_stride, ptr(radii),
              ptr(means2d), ptr(depths), ptr(conics), ptr(comps), ptr(colors), color_stride,
              depth_channel, activations, ptr(opac_act), tile_w, tile_h, ptr(tile_counts),
-             _stream())
+             ptr(records), _stream())
         ctx.cfg = cfg
         ctx.split = sh_b is not None
         ctx.save_for_backward(means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii,
@@ -174,13 +176,15 @@ class _ProjectSH(torch.autograd.Function):
             opac_act = torch.empty(0, device=dev)
         if tile_counts is None:
             tile_counts = torch.empty(0, dtype=torch.int32, device=dev)
-        ctx.mark_non_differentiable(radii, tile_counts)
+        if records is None:
+            records = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(radii, tile_counts, records)
         ctx.set_materialize_grads(False)
-        return radii, means2d, depths, conics, comps, colors, opac_act, tile_counts
+        return radii, means2d, depths, conics, comps, colors, opac_act, tile_counts, records
 
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_colors, v_opac_act,
-                 _v_tc):
+                 _v_tc, _v_rec):
         (width, height, eps2d, near, far, radius_clip, calc_comp, sh_degree, color_stride,
          depth_channel, activations, tile_w, tile_h) = ctx.cfg
         (means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii,
@@ -322,33 +326,37 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order,
-                flatten_ids, cfg):
+                flatten_ids, records, cfg):
         width, height, tile_w, tile_h, CH, absgrad = cfg
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
         color_stride = colors.shape[-1]
+        per_cam = int(opacities.dim() == 2)
+        if records is None or records.numel() != C * N * GRAD_ROW:
+            # caller-supplied colours / opacities: pack the compositing records here
+            records = torch.empty(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
+            call("gsr_pack_records", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
+                 ptr(opacities), per_cam, ptr(records), _stream())
         render_colors = torch.empty(C, height, width, CH, dtype=torch.float32, device=dev)
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
-        per_cam = int(opacities.dim() == 2)
-        call("gsr_rasterize_fwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
-             ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
-             ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_colors),
+        call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
+             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_colors),
              ptr(render_alphas), ptr(last_ids), _stream())
         ctx.cfg = cfg
-        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, tile_offsets,
-                              tile_order, flatten_ids, render_alphas, last_ids)
+        ctx.shape = (C, N, color_stride, per_cam)
+        ctx.save_for_backward(means2d, backgrounds, tile_offsets, tile_order, flatten_ids,
+                              render_alphas, last_ids, records)
         ctx.mark_non_differentiable(last_ids)
         return render_colors, render_alphas, last_ids
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas, _v_last):
         width, height, tile_w, tile_h, CH, absgrad = ctx.cfg
-        (means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order, flatten_ids,
-         render_alphas, last_ids) = ctx.saved_tensors
-        C, N = means2d.shape[0], means2d.shape[1]
+        (means2d, backgrounds, tile_offsets, tile_order, flatten_ids, render_alphas, last_ids,
+         records) = ctx.saved_tensors
+        C, N, color_stride, per_cam = ctx.shape
         dev = means2d.device
-        color_stride = colors.shape[-1]
         if v_render_colors is None:
             v_render_colors = torch.zeros(C, height, width, CH, dtype=torch.float32, device=dev)
         if v_render_alphas is None:
@@ -356,10 +364,8 @@ class _Rasterize(torch.autograd.Function):
         v_render_colors = _f32c(v_render_colors)
         v_render_alphas = _f32c(v_render_alphas)
         rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
-        per_cam = int(opacities.dim() == 2)
-        call("gsr_rasterize_bwd", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
-             ptr(opacities), per_cam, ptr(backgrounds), width, height, tile_w, tile_h,
-             ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_alphas),
+        call("gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
+             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_alphas),
              ptr(last_ids), ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows),
              _stream())
         v_means2d = rows[:, GR_MEAN2D:GR_MEAN2D + 2].view(C, N, 2)
@@ -374,7 +380,7 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             T_final = 1.0 - render_alphas
             v_bg = (v_render_colors * T_final).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -482,7 +488,7 @@ def rasterization(
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
            float(radius_clip), bool(antialiased), int(sh_degree) if use_sh else -1, color_stride,
            depth_channel, activations, tile_w, tile_h)
-    radii, means2d, depths, conics, comps, sh_colors, opac_act, tile_counts = _ProjectSH.apply(
+    radii, means2d, depths, conics, comps, sh_colors, opac_act, tile_counts, records = _ProjectSH.apply(
         means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg)
 
     if activations & ACT_SIGMOID_OPAC:
@@ -523,7 +529,8 @@ def rasterization(
 
     rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
     render_colors, render_alphas, _last = _Rasterize.apply(
-        means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids, rcfg)
+        means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids,
+        records if use_sh else None, rcfg)
 
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat(

@@ -82,6 +82,7 @@ int gsr_project_fwd(int C, int N, const float *means, const float *quats, const 
                     float *opacities_out /* [N] activated opacities (with GSR_ACT_SIGMOID_OPAC) */,
                     int tile_w, int tile_h,
                     int32_t *tile_counts /* NULL, or [C*tile_h*tile_w]: fused gsr_isect_count */,
+                    float *records /* NULL, or [C*N,16]: packed compositing records */,
                     void *stream);
 
 /* Backward of gsr_project_fwd. grad_rows is the [C*N, GSR_GRAD_ROW] scratch
@@ -132,27 +133,29 @@ int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
 
 /* ---------------------------------------------------------------------------
  * A6 / A7: alpha compositing, one wave64 per 16x16 tile (four 8x8 quadrants,
- * one pixel of each per lane). opacities is [N] (opac_per_camera = 0) or
- * [C,N] (1). backgrounds [C,CH] or NULL. last_ids [C,H,W] int32 is the flat
- * index (into flatten_ids) of the last Gaussian blended into a pixel, -1 if
+ * one pixel of each per lane). backgrounds [C,CH] or NULL. last_ids [C,H,W] int32 is
+ * the flat index (into flatten_ids) of the last Gaussian blended into a pixel, -1 if
  * none. tile_order (from gsr_isect_scan) is the order workgroups take tiles in;
  * NULL = natural order.
  * --------------------------------------------------------------------------*/
-int gsr_rasterize_fwd(int C, int N, int CH, const float *means2d, const float *conics,
-                      const float *colors, int color_stride, const float *opacities,
-                      int opac_per_camera, const float *backgrounds, int width, int height,
-                      int tile_w, int tile_h, const int32_t *tile_offsets,
+/* Compositing reads ONE packed 64-byte record per (camera, Gaussian):
+ *   float[16] = {mx, my, conic a, b | conic c, opacity, col0, col1 | col2, col3, col4, - | pad}
+ * gsr_project_fwd writes the records on the SH path; gsr_pack_records builds them
+ * from separate arrays (caller-supplied colours; opacities [N] or [C,N]). */
+#define GSR_REC_FLOATS 16
+int gsr_pack_records(int C, int N, int CH, const float *means2d, const float *conics,
+                     const float *colors, int color_stride, const float *opacities,
+                     int opac_per_camera, float *records, void *stream);
+int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds, int width,
+                      int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *flatten_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
                       void *stream);
-int gsr_rasterize_bwd(int C, int N, int CH, const float *means2d, const float *conics,
-                      const float *colors, int color_stride, const float *opacities,
-                      int opac_per_camera, const float *backgrounds, int width, int height,
-                      int tile_w, int tile_h, const int32_t *tile_offsets,
+int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds, int width,
+                      int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *flatten_ids,
                       const float *render_alphas, const int32_t *last_ids,
-                      const float *v_render_colors,
-                      const float *v_render_alphas, int absgrad,
+                      const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *grad_rows /* [C*N,16], zeroed by caller, accumulated */, void *stream);
 
 /* ---------------------------------------------------------------------------
