@@ -60,14 +60,23 @@ def algorithmic_bytes(C, N, V, I, P, d, D, n_tiles):
     return fwd, bwd
 
 
-def cpu_baseline(sample_n: int = 20_000):
-    """CPU oracle (a port: the reference has no CPU rasterizer, runner.py:153
-    hard-codes cuda) timed on a bounded sample of the same workload."""
+def _host_cores() -> int:
+    """Cores this process may actually use (cgroup / affinity aware), capped at 16:
+    os.cpu_count() reports every hardware thread of the host, and oversubscribing
+    torch's intra-op pool with them makes the CPU leg take minutes."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def _cpu_baseline_worker(sample_n: int):
     import torch
 
     from oracle import rasterization_oracle as O
     from tests import scenes
-    cores = os.cpu_count() or 1
+    cores = _host_cores()
     torch.set_num_threads(cores)
     sc = scenes.make_scene(N_GAUSS, 0)
     sc = {k: v[:sample_n].clone().requires_grad_(True) for k, v in sc.items()}
@@ -79,13 +88,31 @@ def cpu_baseline(sample_n: int = 20_000):
                                sh_degree=SH_DEGREE)
     (rc - target).abs().mean().backward()
     dt = time.perf_counter() - t0
-    # linear extrapolation in the Gaussian count (optimistic for the CPU)
-    return {
-        "value": (1.0 / dt) * (sample_n / N_GAUSS), "unit": "iters/s", "cores": cores,
-        "kind": "port",
-        "sample": (f"oracle/rasterization_oracle.py fwd+bwd, first {sample_n} of the 1M Gaussians, "
-                   f"1 view {WIDTH}x{HEIGHT}, {dt:.1f} s measured, scaled x{sample_n}/{N_GAUSS}"),
-    }
+    print(json.dumps({"dt": dt, "cores": cores}))
+
+
+def cpu_baseline(sample_n: int = 5_000, budget_s: float = 150.0):
+    """CPU oracle (a port: the reference has no CPU rasterizer, runner.py:153
+    hard-codes cuda) timed on a bounded sample of the same workload, in a child
+    process with a hard time budget so the default bench always finishes."""
+    import subprocess
+    base = {"unit": "iters/s", "kind": "port", "cores": _host_cores()}
+    try:
+        out = subprocess.run(
+            [sys.executable, "-c",
+             f"import sys; sys.path.insert(0, {str(ROOT)!r}); import bench; bench._cpu_baseline_worker({sample_n})"],
+            capture_output=True, text=True, timeout=budget_s, cwd=str(ROOT))
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # timeout / failure: report it, never hang the bench
+        return {**base, "value": None,
+                "sample": f"CPU oracle did not finish within {budget_s:.0f} s ({type(e).__name__})"}
+    dt = rec["dt"]
+    return {**base, "cores": rec["cores"],
+            # linear extrapolation in the Gaussian count (optimistic for the CPU)
+            "value": (1.0 / dt) * (sample_n / N_GAUSS),
+            "sample": (f"oracle/rasterization_oracle.py fwd+bwd, first {sample_n} of the 1M Gaussians, "
+                       f"1 view {WIDTH}x{HEIGHT}, {dt:.1f} s measured on {rec['cores']} threads, "
+                       f"scaled x{sample_n}/{N_GAUSS}")}
 
 
 def main():
