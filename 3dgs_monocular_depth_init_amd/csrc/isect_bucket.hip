@@ -1,0 +1,287 @@
+// isect_bucket.hip -- A5, second generation: tile lists without per-intersection
+// global atomics.
+//
+// isect.hip buckets intersections per tile with one returning global atomic per
+// (tile, Gaussian) in the count pass and another in the emit pass: ~5.4 M
+// memory-side atomics per 1080p frame at 1 M Gaussians, which run at the chip's
+// fixed ~20 G requests/s (0.2 ms) whatever else the kernels do. Here the first
+// radix digit is a BUCKET of 8 horizontally adjacent tiles (1 020 per 1080p
+// camera): every 1024-thread workgroup histograms its slice of the Gaussians in
+// LDS and touches global memory with one atomic per non-empty bucket (~1e5 per
+// frame); each bucket is then sorted INSIDE LDS by the composite key
+//   [63:61] tile-in-bucket | [60:30] depth bits (sign dropped) | [29:0] g
+// which yields, in one pass, the per-tile start offsets and the depth-sorted
+// (ties by g) lists -- the same order as isect.hip / a stable global sort.
+#include "common.h"
+
+namespace gsr {
+
+constexpr int BK_TILES = 8;              // tiles per bucket (along x)
+constexpr int BK_MAX_BUCKETS = 8192;     // LDS: 2 x 4 B x buckets = 64 KB
+constexpr int BK_SORT_CAP = 8192;        // entries sorted in LDS per bucket (64 KB)
+constexpr int BK_THREADS = 1024;
+
+__device__ __forceinline__ uint64_t bk_key(int tloc, float depth, uint32_t g) {
+  return ((uint64_t)tloc << 61) | ((uint64_t)(__float_as_uint(depth) & 0x7fffffffu) << 30) |
+         (uint64_t)(g & 0x3fffffffu);
+}
+
+// Walk the buckets a Gaussian's tile rectangle touches: f(bucket, first tile x, last tile x + 1, y)
+template <typename F>
+__device__ __forceinline__ void for_each_bucket(int c, int x0, int x1, int y0, int y1, int bw,
+                                                int tile_h, F &&f) {
+  for (int y = y0; y < y1; ++y) {
+    const int row = (c * tile_h + y) * bw;
+    for (int bx = x0 / BK_TILES; bx <= (x1 - 1) / BK_TILES; ++bx)
+      f(row + bx, max(x0, bx * BK_TILES), min(x1, (bx + 1) * BK_TILES), y);
+  }
+}
+
+// Pass 1: entries per bucket. Each workgroup owns a contiguous slice of the pairs.
+__global__ void __launch_bounds__(BK_THREADS)
+bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
+                    const int32_t *__restrict__ radii, int tile_w, int tile_h, int bw,
+                    int n_buckets, int64_t chunk, int32_t *__restrict__ bucket_counts) {
+  extern __shared__ int32_t hist[];
+  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) hist[b] = 0;
+  __syncthreads();
+  const int64_t total = (int64_t)C * N;
+  const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
+  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
+    int x0, x1, y0, y1;
+    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
+    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h,
+                    [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS)
+    if (hist[b] > 0) atomicAdd(&bucket_counts[b], hist[b]);
+}
+
+// Pass 2: scatter the composite keys into their buckets (unordered inside a bucket).
+__global__ void __launch_bounds__(BK_THREADS)
+bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
+                   const int32_t *__restrict__ radii, const float *__restrict__ depths,
+                   int tile_w, int tile_h, int bw, int n_buckets, int64_t chunk,
+                   const int32_t *__restrict__ bucket_offsets, int32_t *__restrict__ bucket_cursor,
+                   uint64_t *__restrict__ keys, int64_t capacity) {
+  extern __shared__ int32_t lds[];
+  int32_t *hist = lds, *base = lds + n_buckets;
+  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) hist[b] = 0;
+  __syncthreads();
+  const int64_t total = (int64_t)C * N;
+  const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
+  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
+    int x0, x1, y0, y1;
+    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
+    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h,
+                    [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+  }
+  __syncthreads();
+  // reserve this workgroup's range in every bucket it feeds (one atomic per bucket)
+  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) {
+    const int h = hist[b];
+    base[b] = (h > 0) ? bucket_offsets[b] + atomicAdd(&bucket_cursor[b], h) : 0;
+    hist[b] = 0;   // becomes the local cursor
+  }
+  __syncthreads();
+  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
+    int x0, x1, y0, y1;
+    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
+    const float d = depths[g];
+    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h, [&](int b, int xa, int xb, int) {
+      const int n = xb - xa;
+      const int64_t p = (int64_t)base[b] + atomicAdd(&hist[b], n);
+      for (int k = 0; k < n; ++k)
+        if (p + k < capacity) keys[p + k] = bk_key((xa + k) & (BK_TILES - 1), d, (uint32_t)g);
+    });
+  }
+}
+
+template <typename Ptr>
+__device__ __forceinline__ void bk_bitonic(Ptr data, int L, int tid) {
+  int n_pad = 1;
+  while (n_pad < L) n_pad <<= 1;
+  for (int k = 2; k <= n_pad; k <<= 1) {
+    const int half = k >> 1;
+    for (int t = tid; t < (n_pad >> 1); t += BK_THREADS) {
+      const int blk = t / half, off = t - blk * half;
+      const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+      if (hi < L) {
+        const uint64_t a = data[lo], b = data[hi];
+        if (a > b) { data[lo] = b; data[hi] = a; }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j >= 1; j >>= 1) {
+      for (int t = tid; t < (n_pad >> 1); t += BK_THREADS) {
+        const int blk = t / j, off = t - blk * j;
+        const int lo = 2 * j * blk + off, hi = lo + j;
+        if (hi < L) {
+          const uint64_t a = data[lo], b = data[hi];
+          if (a > b) { data[lo] = b; data[hi] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Pass 3: one workgroup per bucket: sort, emit flatten_ids and the tile offsets.
+__global__ void __launch_bounds__(BK_THREADS)
+bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
+                   const int32_t *__restrict__ bucket_order, uint64_t *__restrict__ keys,
+                   int32_t *__restrict__ flatten_ids, int32_t *__restrict__ tile_offsets,
+                   int n_tiles) {
+  __shared__ uint64_t sk[BK_SORT_CAP];
+  const int tid = threadIdx.x;
+  const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
+  const int s = bucket_offsets[b], e = bucket_offsets[b + 1], L = e - s;
+  const bool in_lds = L <= BK_SORT_CAP;
+  if (L > 0) {
+    if (in_lds) {
+      for (int t = tid; t < L; t += BK_THREADS) sk[t] = keys[s + t];
+      __syncthreads();
+      bk_bitonic(sk, L, tid);
+      for (int t = tid; t < L; t += BK_THREADS) {
+        const uint64_t k = sk[t];
+        keys[s + t] = k;
+        flatten_ids[s + t] = (int32_t)(k & 0x3fffffffu);
+      }
+    } else {   // longer than the LDS sorter: same network in global memory (slow, still exact)
+      bk_bitonic(keys + s, L, tid);
+      for (int t = tid; t < L; t += BK_THREADS)
+        flatten_ids[s + t] = (int32_t)(keys[s + t] & 0x3fffffffu);
+      __syncthreads();
+    }
+  }
+  // start offset of each of the bucket's tiles = first entry whose tile-in-bucket >= t
+  const int row = b / bw, bx = b - row * bw;          // row = cam*tile_h + ty
+  if (tid < BK_TILES) {
+    const int tx = bx * BK_TILES + tid;
+    if (tx < tile_w) {
+      int lo = 0, hi = L;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t k = in_lds ? sk[mid] : keys[s + mid];
+        if ((int)(k >> 61) < tid) lo = mid + 1; else hi = mid;
+      }
+      tile_offsets[row * tile_w + tx] = s + lo;
+    }
+  }
+  if (b == n_buckets - 1 && tid == 0) tile_offsets[n_tiles] = e;
+}
+
+// tile_order (longest list first) from finished tile offsets; one workgroup.
+constexpr int ORD_BUCKETS = 64;
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int n, const int32_t *__restrict__ tile_offsets, int32_t *__restrict__ tile_order) {
+  __shared__ int32_t hist[ORD_BUCKETS];
+  const int tid = threadIdx.x;
+  auto cls = [&](int t) {
+    const int len = tile_offsets[t + 1] - tile_offsets[t];
+    return ORD_BUCKETS - 1 - min(ORD_BUCKETS - 1, (len + 31) >> 5);
+  };
+  if (tid < ORD_BUCKETS) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) atomicAdd(&hist[cls(t)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < ORD_BUCKETS; ++b) {
+      const int c = hist[b];
+      hist[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) tile_order[atomicAdd(&hist[cls(t)], 1)] = t;
+}
+
+static inline int bk_grid(int64_t total, int64_t *chunk) {
+  int g = (int)ceil_div64(total, 4096);
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  *chunk = ceil_div64(total, g);
+  return g;
+}
+
+}  // namespace gsr
+
+extern "C" int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int *n_buckets_out) {
+  const int bw = gsr::ceil_div(tile_w, gsr::BK_TILES);
+  if (bw_out) *bw_out = bw;
+  if (n_buckets_out) *n_buckets_out = C * tile_h * bw;
+  return (int64_t)C * tile_h * bw <= gsr::BK_MAX_BUCKETS ? GSR_OK : GSR_ECAPACITY;
+}
+
+extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii,
+                                int tile_w, int tile_h, int32_t *bucket_counts, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && bucket_counts, "bucket_count: bad arguments");
+  int bw, nb;
+  if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
+    gsr::set_error("bucket_count: %d buckets exceed the LDS histogram (%d)", nb, gsr::BK_MAX_BUCKETS);
+    return GSR_ECAPACITY;
+  }
+  GSR_REQUIRE((int64_t)C * N < (1LL << 30), "bucket_count: C*N must be < 2^30 (composite key)");
+  if (nb > 0)
+    GSR_CHECK_HIP(hipMemsetAsync(bucket_counts, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+  const int64_t total = (int64_t)C * N;
+  if (total == 0 || nb == 0) return GSR_OK;
+  GSR_REQUIRE(means2d && radii, "bucket_count: null pointer");
+  int64_t chunk;
+  const int grid = gsr::bk_grid(total, &chunk);
+  hipLaunchKernelGGL(gsr::bucket_count_kernel, dim3(grid), dim3(gsr::BK_THREADS),
+                     sizeof(int32_t) * nb, (hipStream_t)stream, C, N, means2d, radii, tile_w, tile_h,
+                     bw, nb, chunk, bucket_counts);
+  GSR_CHECK_LAUNCH("bucket_count");
+  return GSR_OK;
+}
+
+extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii,
+                               const float *depths, int tile_w, int tile_h,
+                               const int32_t *bucket_offsets, int32_t *bucket_cursor,
+                               uint64_t *keys, int64_t capacity, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && capacity >= 0, "bucket_emit: bad sizes");
+  int bw, nb;
+  if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
+    gsr::set_error("bucket_emit: %d buckets exceed the LDS histogram", nb);
+    return GSR_ECAPACITY;
+  }
+  const int64_t total = (int64_t)C * N;
+  if (total == 0 || nb == 0) return GSR_OK;
+  GSR_REQUIRE(means2d && radii && depths && bucket_offsets && bucket_cursor && (keys || capacity == 0),
+              "bucket_emit: null pointer");
+  GSR_CHECK_HIP(hipMemsetAsync(bucket_cursor, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+  int64_t chunk;
+  const int grid = gsr::bk_grid(total, &chunk);
+  hipLaunchKernelGGL(gsr::bucket_emit_kernel, dim3(grid), dim3(gsr::BK_THREADS),
+                     2 * sizeof(int32_t) * nb, (hipStream_t)stream, C, N, means2d, radii, depths,
+                     tile_w, tile_h, bw, nb, chunk, bucket_offsets, bucket_cursor, keys, capacity);
+  GSR_CHECK_LAUNCH("bucket_emit");
+  return GSR_OK;
+}
+
+extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
+                               const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
+                               int32_t *tile_offsets, int32_t *tile_order, void *stream) {
+  GSR_REQUIRE(C >= 0 && tile_w > 0 && tile_h > 0, "bucket_sort: bad sizes");
+  int bw, nb;
+  if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
+    gsr::set_error("bucket_sort: %d buckets exceed the LDS histogram", nb);
+    return GSR_ECAPACITY;
+  }
+  if (nb == 0) return GSR_OK;
+  GSR_REQUIRE(bucket_offsets && tile_offsets, "bucket_sort: null pointer");
+  const int n_tiles = C * tile_w * tile_h;
+  hipLaunchKernelGGL(gsr::bucket_sort_kernel, dim3(nb), dim3(gsr::BK_THREADS), 0,
+                     (hipStream_t)stream, nb, tile_w, bw, bucket_offsets, bucket_order, keys,
+                     flatten_ids, tile_offsets, n_tiles);
+  GSR_CHECK_LAUNCH("bucket_sort");
+  if (tile_order) {
+    hipLaunchKernelGGL(gsr::tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
+                       tile_offsets, tile_order);
+    GSR_CHECK_LAUNCH("tile_order");
+  }
+  return GSR_OK;
+}

@@ -297,6 +297,9 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
     C, N = depths.shape
     dev = depths.device
     n_tiles = C * tile_w * tile_h
+    if (tile_counts is None or tile_counts.numel() == 0) and not want_tiles_per_gauss \
+            and bucket_layout_ok(C, N, tile_w, tile_h):
+        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h)
     counted = tile_counts is not None and tile_counts.numel() == n_tiles and not want_tiles_per_gauss
     if not counted:
         tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
@@ -318,6 +321,36 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
         call("gsr_tile_sort", n_tiles, ptr(tile_offsets), ptr(tile_order), ptr(keys),
              ptr(flatten_ids), ptr(big_list), st)
     return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], tpg
+
+
+def bucket_layout_ok(C: int, N: int, tile_w: int, tile_h: int) -> bool:
+    """The bucketed tile-list builder needs <= 8192 buckets (LDS histogram) and C*N < 2^30."""
+    return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 30)
+
+
+@torch.no_grad()
+def _isect_bucketed(means2d, radii, depths, tile_w, tile_h):
+    """isect_bucket.hip: buckets of 8 tiles, LDS histograms, one LDS sort per bucket."""
+    C, N = depths.shape
+    dev = depths.device
+    n_tiles = C * tile_w * tile_h
+    n_buckets = C * tile_h * ((tile_w + 7) // 8)
+    st = _stream()
+    counts = torch.empty(n_buckets, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
+    order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
+    call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), st)
+    call("gsr_isect_scan", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
+    n_isects = int(offsets[-1].item())               # the one host sync of the step
+    keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
+         ptr(offsets), ptr(counts), ptr(keys), n_isects, st)
+    call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
+         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), st)
+    return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
 
 
 # --------------------------------------------------------------------------- #
@@ -485,9 +518,12 @@ def rasterization(
         activations = ACT_EXP_SCALES | (0 if antialiased else ACT_SIGMOID_OPAC)
         if antialiased:
             opacities = torch.sigmoid(opacities)
+    # the bucketed tile-list builder does its own (LDS) counting; otherwise the per-tile
+    # count pass is fused into the projection kernel
+    fuse_count = not bucket_layout_ok(C, N, tile_w, tile_h)
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane),
            float(radius_clip), bool(antialiased), int(sh_degree) if use_sh else -1, color_stride,
-           depth_channel, activations, tile_w, tile_h)
+           depth_channel, activations, tile_w if fuse_count else 0, tile_h if fuse_count else 0)
     radii, means2d, depths, conics, comps, sh_colors, opac_act, tile_counts, records = _ProjectSH.apply(
         means, quats, scales, opacities, sh_a, sh_b, viewmats, Ks, campos, cfg)
 

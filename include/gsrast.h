@@ -138,6 +138,27 @@ int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
  * none. tile_order (from gsr_isect_scan) is the order workgroups take tiles in;
  * NULL = natural order.
  * --------------------------------------------------------------------------*/
+/* A5, bucketed variant (isect_bucket.hip): same outputs as count/scan/emit/sort
+ * above -- tile_offsets, flatten_ids in (depth, g) order per tile -- without one
+ * global atomic per intersection: the first digit is a bucket of 8 tiles along x.
+ *   gsr_bucket_layout : buckets per row (bw) and in total; GSR_ECAPACITY when the
+ *                       total exceeds the LDS histogram (8192) -> use the calls above.
+ *   gsr_bucket_count  : bucket_counts[n_buckets] (zeroed inside); scan them with
+ *                       gsr_isect_scan (its tile_order output = bucket work order).
+ *   gsr_bucket_emit   : composite keys (tile-in-bucket | depth | g) into the buckets;
+ *                       bucket_cursor[n_buckets] is scratch. Needs C*N < 2^30.
+ *   gsr_bucket_sort   : sorts every bucket in LDS, writes flatten_ids[n_isects],
+ *                       tile_offsets[n_tiles+1] and (optional) tile_order[n_tiles]. */
+int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int *n_buckets_out);
+int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_w,
+                     int tile_h, int32_t *bucket_counts, void *stream);
+int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                    int tile_w, int tile_h, const int32_t *bucket_offsets, int32_t *bucket_cursor,
+                    uint64_t *keys, int64_t capacity, void *stream);
+int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
+                    const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
+                    int32_t *tile_offsets, int32_t *tile_order, void *stream);
+
 /* Compositing reads ONE packed 64-byte record per (camera, Gaussian):
  *   float[16] = {mx, my, conic a, b | conic c, opacity, col0, col1 | col2, col3, col4, - | pad}
  * gsr_project_fwd writes the records on the SH path; gsr_pack_records builds them

@@ -254,3 +254,31 @@ def test_tree_reduce8(R):
     assert sorted(set(idx.tolist())) == list(range(8))
     assert torch.allclose(out[:64].cpu().double(), tot[idx], atol=1e-4)
     assert torch.allclose(out[64:].cpu().double(), tot[0].expand(64), atol=1e-4)
+
+
+def test_bucketed_and_atomic_tile_lists_agree(R):
+    """isect_bucket.hip (LDS histograms + per-bucket LDS sort) and isect.hip (per-tile
+    atomics + per-tile sort) must produce identical offsets and lists."""
+    sc = scenes.make_scene(20000, 12, box=(1.2, 0.8, 0.4), scale_mean=0.02)
+    W, H = 300, 200                                   # 19 x 13 tiles: last bucket of a row is partial
+    vm, K = scenes.cameras([0, 25, 50], width=W, height=H, f=250.0, dist=2.5)
+    g = {k: sc[k].cuda() for k in ("means", "quats", "scales", "opacities")}
+    col = torch.cat([sc["sh0"], sc["shN"]], 1).cuda()
+    _, _, meta = R.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], col, vm.cuda(),
+                                 K.cuda(), W, H, sh_degree=1, packed=False)
+    tw, th = meta["tile_width"], meta["tile_height"]
+    assert R.bucket_layout_ok(3, 20000, tw, th)
+    m2d, radii, depths = meta["means2d"].detach(), meta["radii"], meta["depths"].detach()
+    off_b, ord_b, ids_b, _, _ = R.isect_tiles_sorted(m2d, radii, depths, tw, th)
+    off_a, ord_a, ids_a, _, tpg = R.isect_tiles_sorted(m2d, radii, depths, tw, th, want_tiles_per_gauss=True)
+    assert torch.equal(off_a, off_b) and torch.equal(ids_a, ids_b)
+    assert int(tpg.sum()) == ids_a.numel() == int(off_a[-1])
+    n_tiles = 3 * tw * th
+    for o in (ord_a, ord_b):                          # both work orders are permutations, longest first
+        assert sorted(o.cpu().tolist()) == list(range(n_tiles))
+        lens = (off_a[1:] - off_a[:-1])[o.long()]
+        assert (((lens[:-1] + 31) // 32) >= ((lens[1:] + 31) // 32)).all()
+    # and against the oracle's stable global sort
+    _, ids, flat = O.isect_tiles_fast(m2d.cpu(), radii.cpu(), depths.cpu(), 16, tw, th)
+    assert torch.equal(ids_b.cpu(), flat)
+    assert torch.equal(off_b[:-1].cpu().view(3, th, tw), O.isect_offset_encode(ids, 3, tw, th))
