@@ -32,7 +32,7 @@ SIGNATURES = {
     "gsr_bucket_layout": [_i, _i, _i, _p, _p],
     "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _p],
     "gsr_bucket_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
-    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
     "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "gsr_rasterize_bwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
@@ -103,11 +103,12 @@ def load():
 # call is bracketed by events on torch's current stream (the stream the kernels
 # are launched on); read with kernel_times_ms() after a synchronize.
 TIMERS = None
+TIMER_ONLY = None      # optional set of entry-point names to restrict the timing to
 
 
 def call(name: str, *args) -> None:
     lib = load()
-    if TIMERS is not None:
+    if TIMERS is not None and (TIMER_ONLY is None or name in TIMER_ONLY):
         import torch
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)

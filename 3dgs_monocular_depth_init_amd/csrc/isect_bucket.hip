@@ -132,11 +132,15 @@ __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
                    const int32_t *__restrict__ bucket_order, uint64_t *__restrict__ keys,
                    int32_t *__restrict__ flatten_ids, int32_t *__restrict__ tile_offsets,
-                   int n_tiles) {
+                   int n_tiles, int capacity) {
   __shared__ uint64_t sk[BK_SORT_CAP];
   const int tid = threadIdx.x;
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
-  const int s = bucket_offsets[b], e = bucket_offsets[b + 1], L = e - s;
+  // `capacity` = entries the key / id buffers hold. The caller may size them from the
+  // previous frame without waiting for this frame's total: everything is clamped so an
+  // overflowing frame yields truncated (then discarded) lists, never an out-of-bounds access.
+  const int s = min(bucket_offsets[b], capacity), e = min(bucket_offsets[b + 1], capacity);
+  const int L = e - s;
   const bool in_lds = L <= BK_SORT_CAP;
   if (L > 0) {
     if (in_lds) {
@@ -264,7 +268,8 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
 
 extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
                                const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
-                               int32_t *tile_offsets, int32_t *tile_order, void *stream) {
+                               int32_t *tile_offsets, int32_t *tile_order, int64_t capacity,
+                               void *stream) {
   GSR_REQUIRE(C >= 0 && tile_w > 0 && tile_h > 0, "bucket_sort: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -272,11 +277,12 @@ extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *buc
     return GSR_ECAPACITY;
   }
   if (nb == 0) return GSR_OK;
-  GSR_REQUIRE(bucket_offsets && tile_offsets, "bucket_sort: null pointer");
+  GSR_REQUIRE(bucket_offsets && tile_offsets && capacity >= 0, "bucket_sort: bad arguments");
   const int n_tiles = C * tile_w * tile_h;
   hipLaunchKernelGGL(gsr::bucket_sort_kernel, dim3(nb), dim3(gsr::BK_THREADS), 0,
                      (hipStream_t)stream, nb, tile_w, bw, bucket_offsets, bucket_order, keys,
-                     flatten_ids, tile_offsets, n_tiles);
+                     flatten_ids, tile_offsets, n_tiles,
+                     (int)(capacity < 2147483647LL ? capacity : 2147483647LL));
   GSR_CHECK_LAUNCH("bucket_sort");
   if (tile_order) {
     hipLaunchKernelGGL(gsr::tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,

@@ -290,7 +290,8 @@ def inverse4x4(mats: Tensor) -> Tuple[Tensor, Tensor]:
 # --------------------------------------------------------------------------- #
 @torch.no_grad()
 def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
-                       want_tiles_per_gauss: bool = False, tile_counts: Optional[Tensor] = None):
+                       want_tiles_per_gauss: bool = False, tile_counts: Optional[Tensor] = None,
+                       capacity: Optional[int] = None):
     """Returns (tile_offsets [n_tiles+1] int32, tile_order [n_tiles] int32 (longest list
     first), flatten_ids [I] int32, isect_keys [I] int64 (depth_bits<<32 | g, sorted per
     tile), tiles_per_gauss or None)."""
@@ -299,7 +300,7 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
     n_tiles = C * tile_w * tile_h
     if (tile_counts is None or tile_counts.numel() == 0) and not want_tiles_per_gauss \
             and bucket_layout_ok(C, N, tile_w, tile_h):
-        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h)
+        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity)
     counted = tile_counts is not None and tile_counts.numel() == n_tiles and not want_tiles_per_gauss
     if not counted:
         tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
@@ -328,9 +329,32 @@ def bucket_layout_ok(C: int, N: int, tile_w: int, tile_h: int) -> bool:
     return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 30)
 
 
+class _IsectState:
+    """Per-device memory of the last frame's intersection count: lets the next frame
+    size its buffers and launch emit / sort / compositing WITHOUT waiting for its own
+    count to reach the host (the wait is deferred until after those launches, when the
+    GPU has work queued; an overflowing frame is simply rebuilt with larger buffers)."""
+    capacity: Dict[int, int] = {}
+    pinned: Dict[int, Tensor] = {}       # one reusable pinned int32 per device
+
+
+class _PendingIsect:
+    def __init__(self, dev, n_host, event, capacity):
+        self.dev, self.n_host, self.event, self.capacity = dev, n_host, event, capacity
+
+    def resolve(self) -> Tuple[int, bool]:
+        """(n_isects, overflowed). Blocks only until the count + scan kernels are done."""
+        self.event.synchronize()
+        n = int(self.n_host[0])
+        _IsectState.capacity[self.dev.index] = int(n * 1.25) + 8192
+        return n, n > self.capacity
+
+
 @torch.no_grad()
-def _isect_bucketed(means2d, radii, depths, tile_w, tile_h):
-    """isect_bucket.hip: buckets of 8 tiles, LDS histograms, one LDS sort per bucket."""
+def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[int] = None):
+    """isect_bucket.hip: buckets of 8 tiles, LDS histograms, one LDS sort per bucket.
+    With `capacity` the call never blocks: returns full-capacity buffers and a
+    _PendingIsect to resolve after the consumer kernels have been launched."""
     C, N = depths.shape
     dev = depths.device
     n_tiles = C * tile_w * tile_h
@@ -341,16 +365,31 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h):
     order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
     call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), st)
     call("gsr_isect_scan", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
-    n_isects = int(offsets[-1].item())               # the one host sync of the step
-    keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
-    flatten_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    pending = None
+    if capacity is None:
+        n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
+        cap = max(n_isects, 1)
+        _IsectState.capacity[dev.index] = int(n_isects * 1.25) + 8192
+    else:
+        n_host = _IsectState.pinned.get(dev.index)
+        if n_host is None:
+            n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        n_host.copy_(offsets[-1:], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cap = max(int(capacity), 1)
+        pending = _PendingIsect(dev, n_host, ev, cap)
+    keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
-         ptr(offsets), ptr(counts), ptr(keys), n_isects, st)
+         ptr(offsets), ptr(counts), ptr(keys), cap, st)
     call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
-         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), st)
-    return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
+         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, st)
+    if pending is None:
+        return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
+    return tile_offsets, tile_order, flatten_ids, keys, pending
 
 
 # --------------------------------------------------------------------------- #
@@ -559,14 +598,25 @@ def rasterization(
             backgrounds = torch.zeros(C, 1, dtype=torch.float32, device=means.device)
         backgrounds = backgrounds.contiguous()
 
-    tile_offsets, tile_order, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
-        means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False,
-        tile_counts=tile_counts)
-
     rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
-    render_colors, render_alphas, _last = _Rasterize.apply(
-        means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids,
-        records if use_sh else None, rcfg)
+    # Tile lists + compositing. When the bucketed builder applies and a previous frame
+    # told us how many intersections to expect, nothing here waits for the GPU until the
+    # compositing forward has been queued (see _IsectState).
+    capacity = _IsectState.capacity.get(means.device.index) if not fuse_count else None
+    while True:
+        tile_offsets, tile_order, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
+            means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False,
+            tile_counts=tile_counts, capacity=capacity)
+        render_colors, render_alphas, _last = _Rasterize.apply(
+            means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids,
+            records if use_sh else None, rcfg)
+        if not isinstance(tpg, _PendingIsect):
+            break
+        n_isects, overflowed = tpg.resolve()
+        if not overflowed:
+            flatten_ids, isect_keys, tpg = flatten_ids[:n_isects], isect_keys[:n_isects], None
+            break
+        capacity = None        # rare: this frame outgrew the guess -> rebuild, blocking
 
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat(

@@ -180,16 +180,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dom = "gsr_rasterize_bwd"            # dominant kernel: compositing backward (A7)
     for k in range(args.warmup):
         step(k)
     barrier()
+    # timed region: only the dominant kernel is bracketed by events (2 records per step);
+    # the per-kernel breakdown is taken on a few extra, untimed steps afterwards so that
+    # its ~25 event records per step do not sit in the measured host path
     lib.TIMERS = {}
+    lib.TIMER_ONLY = {dom}
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
+    dom_times = lib.kernel_times_ms()
+    lib.TIMERS = {}
+    lib.TIMER_ONLY = None
+    for k in range(5):
+        step(args.warmup + args.steps + k)
+    barrier()
     times = lib.kernel_times_ms()
+    times[dom] = dom_times.get(dom, times.get(dom))
     lib.TIMERS = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -204,8 +216,6 @@ def main():
     fwd_b, bwd_b = algorithmic_bytes(1, N, V, I, P, SH_DEGREE, 3, n_tiles)
     iter_bytes = sum(fwd_b.values()) + sum(bwd_b.values())
     ms_per_step = dt / args.steps * 1e3
-    # dominant kernel: compositing backward (A7)
-    dom = "gsr_rasterize_bwd"
     dom_bytes = bwd_b["raster_bwd_pix"] + bwd_b["raster_bwd_gather"] + bwd_b["raster_bwd_atomics"]
     dom_ms = times.get(dom, (0, float("nan")))[1]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None

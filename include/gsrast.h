@@ -157,7 +157,9 @@ int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, co
                     uint64_t *keys, int64_t capacity, void *stream);
 int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
                     const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
-                    int32_t *tile_offsets, int32_t *tile_order, void *stream);
+                    int32_t *tile_offsets, int32_t *tile_order,
+                    int64_t capacity /* entries in keys / flatten_ids; offsets are clamped to it */,
+                    void *stream);
 
 /* Compositing reads ONE packed 64-byte record per (camera, Gaussian):
  *   float[16] = {mx, my, conic a, b | conic c, opacity, col0, col1 | col2, col3, col4, - | pad}

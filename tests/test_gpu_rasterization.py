@@ -282,3 +282,25 @@ def test_bucketed_and_atomic_tile_lists_agree(R):
     _, ids, flat = O.isect_tiles_fast(m2d.cpu(), radii.cpu(), depths.cpu(), 16, tw, th)
     assert torch.equal(ids_b.cpu(), flat)
     assert torch.equal(off_b[:-1].cpu().view(3, th, tw), O.isect_offset_encode(ids, 3, tw, th))
+
+
+def test_deferred_sync_capacity_overflow_is_rebuilt(R):
+    """The tile-list buffers are sized from the previous frame; a frame that outgrows
+    the guess must be rebuilt transparently and give the same result."""
+    sc, vm, K, W, H = _tiny(N=3000)
+    g = {k: sc[k].cuda() for k in ("means", "quats", "scales", "opacities")}
+    col = torch.cat([sc["sh0"], sc["shN"]], 1).cuda()
+    args = (g["means"], g["quats"], g["scales"], g["opacities"], col, vm.cuda(), K.cuda(), W, H)
+    dev = g["means"].device.index
+    R._IsectState.capacity.pop(dev, None)
+    rc0, ra0, m0 = R.rasterization(*args, sh_degree=2, packed=False)        # blocking first frame
+    n = m0["flatten_ids"].numel()
+    assert R._IsectState.capacity[dev] >= n
+    rc1, ra1, m1 = R.rasterization(*args, sh_degree=2, packed=False)        # deferred, fits
+    R._IsectState.capacity[dev] = max(1, n // 3)                            # force an overflow
+    rc2, ra2, m2 = R.rasterization(*args, sh_degree=2, packed=False)
+    for rc, m in ((rc1, m1), (rc2, m2)):
+        assert torch.equal(rc, rc0)
+        assert torch.equal(m["flatten_ids"], m0["flatten_ids"])
+        assert torch.equal(m["isect_offsets"], m0["isect_offsets"])
+    assert R._IsectState.capacity[dev] >= n                                 # re-learnt
