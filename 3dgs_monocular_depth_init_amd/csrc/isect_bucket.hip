@@ -98,42 +98,92 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   }
 }
 
+// All-ascending bitonic network with virtual +inf padding (positions >= L). Pair
+// index t of a step with stride j touches elements inside [128*(t/64), +128) whenever
+// j <= 64, i.e. inside the chunk owned by ONE wave: those steps need no workgroup
+// barrier (a wave's LDS accesses complete in order), only the wide strides do.
+__device__ __forceinline__ void bk_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <typename Ptr>
-__device__ __forceinline__ void bk_bitonic(Ptr data, int L, int tid) {
-  int n_pad = 1;
-  while (n_pad < L) n_pad <<= 1;
-  for (int k = 2; k <= n_pad; k <<= 1) {
-    const int half = k >> 1;
-    for (int t = tid; t < (n_pad >> 1); t += BK_THREADS) {
-      const int blk = t / half, off = t - blk * half;
-      const int lo = blk * k + off, hi = blk * k + k - 1 - off;
-      if (hi < L) {
-        const uint64_t a = data[lo], b = data[hi];
-        if (a > b) { data[lo] = b; data[hi] = a; }
-      }
-    }
-    __syncthreads();
-    for (int j = k >> 2; j >= 1; j >>= 1) {
-      for (int t = tid; t < (n_pad >> 1); t += BK_THREADS) {
-        const int blk = t / j, off = t - blk * j;
-        const int lo = 2 * j * blk + off, hi = lo + j;
-        if (hi < L) {
-          const uint64_t a = data[lo], b = data[hi];
-          if (a > b) { data[lo] = b; data[hi] = a; }
-        }
-      }
-      __syncthreads();
+__device__ __forceinline__ void bk_cmpx(Ptr data, int lo, int hi, int L) {
+  if (hi < L) {
+    const uint64_t a = data[lo], b = data[hi];
+    if (a > b) {
+      data[lo] = b;
+      data[hi] = a;
     }
   }
 }
+template <bool WAVE_LOCAL_OK, typename Ptr>
+__device__ __forceinline__ void bk_bitonic(Ptr data, int L, int tid) {
+  int n_pad = 1;
+  while (n_pad < L) n_pad <<= 1;
+  const int n_pairs = n_pad >> 1;
+  for (int k = 2; k <= n_pad; k <<= 1) {
+    const int half = k >> 1;
+    // mirror step: partners span the whole k-block
+    for (int t = tid; t < n_pairs; t += BK_THREADS) {
+      const int blk = t / half, off = t - blk * half;
+      bk_cmpx(data, blk * k + off, blk * k + k - 1 - off, L);
+    }
+    if (WAVE_LOCAL_OK && k <= 128) bk_wave_sync(); else __syncthreads();
+    for (int j = k >> 2; j >= 1; j >>= 1) {
+      for (int t = tid; t < n_pairs; t += BK_THREADS) {
+        const int blk = t / j, off = t - blk * j;
+        const int lo = 2 * j * blk + off;
+        bk_cmpx(data, lo, lo + j, L);
+      }
+      // wave-only ordering suffices iff THIS step and the NEXT one (stride j/2, or the next
+      // stage's mirror over 2k) both stay inside the wave's own 128-element chunks
+      const bool both_local = WAVE_LOCAL_OK && ((j > 1) ? (j <= 64) : (2 * k <= 128));
+      if (both_local) bk_wave_sync(); else __syncthreads();
+    }
+  }
+  __syncthreads();
+}
 
-// Pass 3: one workgroup per bucket: sort, emit flatten_ids and the tile offsets.
+// One bitonic network per tile segment, run by a group of GT threads; all groups walk
+// the same (k, j) schedule up to n_pad_max so that the workgroup barriers line up.
+template <int GT>
+__device__ __forceinline__ void bk_bitonic_segments(uint64_t *seg, int L, int n_pad_max, int gtid) {
+  int n_pad = 1;
+  while (n_pad < L) n_pad <<= 1;
+  const int n_pairs = n_pad >> 1;
+  for (int k = 2; k <= n_pad_max; k <<= 1) {
+    const int half = k >> 1;
+    if (k <= n_pad)
+      for (int t = gtid; t < n_pairs; t += GT) {
+        const int blk = t / half, off = t - blk * half;
+        bk_cmpx(seg, blk * k + off, blk * k + k - 1 - off, L);
+      }
+    if (k <= 128) bk_wave_sync(); else __syncthreads();
+    for (int j = k >> 2; j >= 1; j >>= 1) {
+      if (k <= n_pad)
+        for (int t = gtid; t < n_pairs; t += GT) {
+          const int blk = t / j, off = t - blk * j;
+          const int lo = 2 * j * blk + off;
+          bk_cmpx(seg, lo, lo + j, L);
+        }
+      const bool both_local = (j > 1) ? (j <= 64) : (2 * k <= 128);
+      if (both_local) bk_wave_sync(); else __syncthreads();
+    }
+  }
+  __syncthreads();
+}
+
+// Pass 3: one workgroup per bucket. The keys are split by tile-in-bucket while they are
+// loaded into LDS (8-bin counting sort), then the 8 tile segments are depth-sorted side
+// by side, each by its own 128-thread group; flatten_ids and the tile offsets follow.
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
                    const int32_t *__restrict__ bucket_order, uint64_t *__restrict__ keys,
                    int32_t *__restrict__ flatten_ids, int32_t *__restrict__ tile_offsets,
                    int n_tiles, int capacity) {
   __shared__ uint64_t sk[BK_SORT_CAP];
+  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], seg_cur[BK_TILES], npad_max_s;
   const int tid = threadIdx.x;
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
   // `capacity` = entries the key / id buffers hold. The caller may size them from the
@@ -141,36 +191,53 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   // overflowing frame yields truncated (then discarded) lists, never an out-of-bounds access.
   const int s = min(bucket_offsets[b], capacity), e = min(bucket_offsets[b + 1], capacity);
   const int L = e - s;
-  const bool in_lds = L <= BK_SORT_CAP;
-  if (L > 0) {
-    if (in_lds) {
-      for (int t = tid; t < L; t += BK_THREADS) sk[t] = keys[s + t];
-      __syncthreads();
-      bk_bitonic(sk, L, tid);
-      for (int t = tid; t < L; t += BK_THREADS) {
-        const uint64_t k = sk[t];
-        keys[s + t] = k;
-        flatten_ids[s + t] = (int32_t)(k & 0x3fffffffu);
-      }
-    } else {   // longer than the LDS sorter: same network in global memory (slow, still exact)
-      bk_bitonic(keys + s, L, tid);
-      for (int t = tid; t < L; t += BK_THREADS)
-        flatten_ids[s + t] = (int32_t)(keys[s + t] & 0x3fffffffu);
-      __syncthreads();
-    }
-  }
-  // start offset of each of the bucket's tiles = first entry whose tile-in-bucket >= t
   const int row = b / bw, bx = b - row * bw;          // row = cam*tile_h + ty
-  if (tid < BK_TILES) {
-    const int tx = bx * BK_TILES + tid;
-    if (tx < tile_w) {
+  if (L <= BK_SORT_CAP) {
+    if (tid < BK_TILES) seg_cnt[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < L; t += BK_THREADS) atomicAdd(&seg_cnt[(int)(keys[s + t] >> 61)], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0, mx = 0;
+      for (int q = 0; q < BK_TILES; ++q) {
+        seg_start[q] = run;
+        seg_cur[q] = run;
+        run += seg_cnt[q];
+        mx = max(mx, seg_cnt[q]);
+      }
+      seg_start[BK_TILES] = run;
+      int np = 1;
+      while (np < mx) np <<= 1;
+      npad_max_s = np;
+    }
+    __syncthreads();
+    for (int t = tid; t < L; t += BK_THREADS) {
+      const uint64_t k = keys[s + t];
+      sk[atomicAdd(&seg_cur[(int)(k >> 61)], 1)] = k;
+    }
+    __syncthreads();
+    const int grp = tid >> 7;                          // 8 groups of 128 threads
+    bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+    for (int t = tid; t < L; t += BK_THREADS) {
+      const uint64_t k = sk[t];
+      keys[s + t] = k;
+      flatten_ids[s + t] = (int32_t)(k & 0x3fffffffu);
+    }
+    if (tid < BK_TILES && bx * BK_TILES + tid < tile_w)
+      tile_offsets[row * tile_w + bx * BK_TILES + tid] = s + seg_start[tid];
+  } else {   // longer than the LDS sorter: one composite-key network in global memory (slow, exact)
+    bk_bitonic<false>(keys + s, L, tid);
+    for (int t = tid; t < L; t += BK_THREADS)
+      flatten_ids[s + t] = (int32_t)(keys[s + t] & 0x3fffffffu);
+    __syncthreads();
+    // start offset of each tile = first entry whose tile-in-bucket >= t
+    if (tid < BK_TILES && bx * BK_TILES + tid < tile_w) {
       int lo = 0, hi = L;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        const uint64_t k = in_lds ? sk[mid] : keys[s + mid];
-        if ((int)(k >> 61) < tid) lo = mid + 1; else hi = mid;
+        if ((int)(keys[s + mid] >> 61) < tid) lo = mid + 1; else hi = mid;
       }
-      tile_offsets[row * tile_w + tx] = s + lo;
+      tile_offsets[row * tile_w + bx * BK_TILES + tid] = s + lo;
     }
   }
   if (b == n_buckets - 1 && tid == 0) tile_offsets[n_tiles] = e;

@@ -200,19 +200,20 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
 __global__ void __launch_bounds__(256)
 l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
               double *__restrict__ sum) {
-  double acc = 0.0;
+  // fp32 partial per thread (a few dozen terms of magnitude <= 1), fp64 across threads
+  float part = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n) {
       const float4 x = *reinterpret_cast<const float4 *>(a + i);
       const float4 y = *reinterpret_cast<const float4 *>(b + i);
-      acc += (double)(fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w));
+      part += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
     } else {
-      for (int64_t k = i; k < n; ++k) acc += (double)fabsf(a[k] - b[k]);
+      for (int64_t k = i; k < n; ++k) part += fabsf(a[k] - b[k]);
     }
   }
   __shared__ double red[4];
-  acc = wave_sum_f64(acc);
+  double acc = wave_sum_f64((double)part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
