@@ -189,7 +189,7 @@ def isect_tiles(
     tile_bits = max(1, math.ceil(math.log2(max(n_tiles, 2))))
     flat = torch.nonzero(tpg.reshape(-1) > 0).reshape(-1)
     keys, vals = [], []
-    depth_bits = depths.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    depth_bits = depths.float().contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
     for g in flat.tolist():
         c, i = divmod(g, N)
         ys = torch.arange(int(y0[c, i]), int(y1[c, i]), dtype=torch.int64)
@@ -237,7 +237,7 @@ def isect_tiles_fast(
     tx = x0.reshape(-1)[g] + local % nxg
     tid = ty * tile_w + tx
     cam = g // N
-    depth_bits = depths.contiguous().view(torch.int32).to(torch.int64).reshape(-1) & 0xFFFFFFFF
+    depth_bits = depths.float().contiguous().view(torch.int32).to(torch.int64).reshape(-1) & 0xFFFFFFFF
     keys = (cam << (32 + tile_bits)) | (tid << 32) | depth_bits[g]
     order = torch.argsort(keys, stable=True)
     return tpg, keys[order], g[order].to(torch.int32)
