@@ -13,12 +13,17 @@ Pinning status:
     align_depth_least_squares / DepthAlignmentLstSqrs (B2), StaticDepthSubsampler
     (B5), AdaptiveDepthSubsampler + helpers (B6), calculate_patch_sizes /
     num_sfm_points_mask (B7), rgb_to_sh, knn (A9).
-  * PARITY UNPINNED (restated from the cited lines only): the RANSAC/MSAC loop
-    (B3), get_valid_sfm_pts / project_and_filter_sfm_pts (B1), the pipeline's
+  * PINNED by a recorded run of the reference's own ransacs.py (8 seeded cases,
+    tests/golden/make_ransac_golden.py -> ransac_golden.npz; that script registers
+    inert placeholders for the two absent third-party NAMES config.py imports for
+    its dataclass fields, nothing else): the RANSAC/MSAC loop (B3) -- iteration
+    count, inlier count, scale/shift and aligned map all reproduce exactly.
+  * PARITY UNPINNED (restated from the cited lines only):
+    get_valid_sfm_pts / project_and_filter_sfm_pts (B1), the pipeline's
     no-segmentation branch (B4), depth_gradient_mask (B8) and the unprojection
-    (B9): their modules import `gs_init_compare.config`, which imports gsplat
-    (absent; ordinary ImportError), and the reference holds no tests or
-    fixtures for them.
+    (B9): points_from_depth.py / pipeline.py import dataset, viewer and
+    segmentation packages that are absent (ordinary ImportError), and the
+    reference holds no tests or fixtures for them.
 """
 from __future__ import annotations
 

@@ -143,6 +143,26 @@ def test_ransac_vs_oracle(loss, seed):
     assert st["iterations"] == it_o
 
 
+@pytest.mark.parametrize("i", range(8))
+def test_ransac_vs_reference_golden(i):
+    """The HIP RANSAC/MSAC against a recorded run of the REFERENCE's own ransacs.py
+    (tests/golden/ransac_golden.npz): same RNG stream, same iteration at which the
+    adaptive stop fires, same consensus set; scale/shift agree to fp32 LSQ accuracy
+    (normal equations in fp64 here, fp32 einsum + pinv in the reference)."""
+    from tests.test_init_oracle_golden import ransac_case
+    Rm = mod("depth_alignment.alignment.ransacs")
+    cfgm = mod("depth_alignment.config")
+    c = ransac_case(i)
+    torch.manual_seed(c["seed"])
+    res, st = Rm._align_depth_ransac_generic(_pd(c["depth"], c["mask"]), c["coords"].cuda(), c["gt"].cuda(),
+                                             c["loss"], cfgm.RansacConfig(**c["cfg"]), return_stats=True)
+    assert st["iterations"] == c["iterations"]
+    assert abs(st["inliers"] - c["inliers"]) <= max(1, 0.005 * c["inliers"])
+    assert st["scale"] == pytest.approx(c["scale_shift"][0], rel=1e-3)
+    assert st["shift"] == pytest.approx(c["scale_shift"][1], rel=1e-2, abs=2e-3)
+    assert torch.allclose(res.aligned_depth.cpu(), c["aligned"], rtol=2e-3, atol=2e-3)
+
+
 def test_ransac_scoring_matches_oracle_for_given_hypotheses():
     """Bit-level check of the scoring kernels on fixed hypotheses (decisions
     depend only on these numbers)."""

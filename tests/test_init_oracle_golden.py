@@ -54,3 +54,30 @@ def test_patch_sizes():
 def test_knn_and_rgb_to_sh():
     assert torch.allclose(IO.knn_dists(_t("knn_pts"), 4), _t("knn_d4"), rtol=1e-5, atol=1e-6)
     assert torch.equal(IO.rgb_to_sh(_t("sh_rgb")), _t("sh_out"))
+
+
+# ---- B3: the reference's own RANSAC / MSAC run (tests/golden/make_ransac_golden.py) ----
+RG = np.load(Path(__file__).resolve().parent / "golden" / "ransac_golden.npz")
+
+
+def ransac_case(i):
+    t = lambda n: torch.from_numpy(RG[f"r{i}_{n}"])
+    thr, max_iters, conf, ssz, min_iters = RG[f"r{i}_cfg"]
+    cfg = dict(inlier_threshold=float(thr), max_iters=int(max_iters), confidence=float(conf),
+               sample_size=int(ssz), min_iters=int(min_iters))
+    return dict(depth=t("depth"), mask=t("mask"), coords=t("coords"), gt=t("gt"),
+                seed=int(RG[f"r{i}_rng_seed"]), loss=str(RG[f"r{i}_loss"]), cfg=cfg,
+                iterations=int(RG[f"r{i}_iterations"]), inliers=int(RG[f"r{i}_inliers"]),
+                scale_shift=RG[f"r{i}_scale_shift"], aligned=t("aligned"))
+
+
+@pytest.mark.parametrize("i", range(int(RG["n_cases"])))
+def test_ransac_oracle_matches_reference_run(i):
+    c = ransac_case(i)
+    torch.manual_seed(c["seed"])
+    s, t, aligned, it, inl = IO.ransac_align(c["depth"], c["coords"], c["gt"], c["loss"],
+                                             IO.RansacConfig(**c["cfg"]))
+    assert it == c["iterations"] and inl == c["inliers"]
+    assert float(s) == pytest.approx(c["scale_shift"][0], rel=1e-7)
+    assert float(t) == pytest.approx(c["scale_shift"][1], rel=1e-7)
+    assert torch.equal(aligned, c["aligned"])
