@@ -33,13 +33,14 @@ class GradSync:
     losses, as with the reference's batch dimension) unless `average=True`."""
 
     def __init__(self, splats, world_size: int, average: bool = False, group=None,
-                 use_arena: bool = True):
+                 use_arena: bool = True, force: bool = False):
         self.splats = splats
         self.world = world_size
         self.average = average
         self.group = group
         self.arena = None
         self.use_arena = use_arena
+        self.force = force              # issue the collective even at world_size 1 (rehearsal)
         self._maybe_build_arena()
 
     def _maybe_build_arena(self) -> None:
@@ -57,7 +58,7 @@ class GradSync:
     def __call__(self) -> None:
         if self.arena is not None:
             self.arena.reset()
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             self._maybe_build_arena()
             return
         names = [n for n in PARAM_ORDER if n in self.splats]

@@ -137,7 +137,10 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # GSR_BENCH_FORCE_DIST=1 (under torchrun with one rank) rehearses the whole RCCL
+    # path -- process group, gradient all-reduce, barrier, max-over-ranks -- on a 1-GPU box
+    use_dist = world > 1 or (os.environ.get("GSR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -162,7 +165,7 @@ def main():
     gen = torch.Generator().manual_seed(2)
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
     cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
-    sync = distributed.GradSync(splats, world) if world > 1 else None
+    sync = distributed.GradSync(splats, world, force=use_dist) if use_dist else None
     info_box = {}
 
     def step(k: int):
@@ -176,7 +179,7 @@ def main():
         info_box["info"] = info
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -203,7 +206,7 @@ def main():
     times = lib.kernel_times_ms()
     times[dom] = dom_times.get(dom, times.get(dom))
     lib.TIMERS = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -255,7 +258,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
