@@ -7,10 +7,11 @@ stream as `torch.cuda.current_stream().cuda_stream`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libgsrast.so"
+_LIB_PATH = Path(os.environ.get("GSRAST_LIB") or Path(__file__).resolve().parent / "lib" / "libgsrast.so")
 _lock = threading.Lock()
 _lib = None
 

@@ -68,6 +68,33 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float,
                             __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// DPP steps the compiler does not fold into one instruction (it emits v_mov 0 +
+// v_mov_dpp + v_add for them): written out. The leading s_nop covers the
+// VALU-write -> DPP-read hazard, which the compiler cannot see inside the asm.
+__device__ __forceinline__ float dpp_add_half_mirror(float v) {
+  float r;
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf"
+      : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ float dpp_add_bcast15(float v) {   // rows 1,3 += lane 15 of rows 0,2
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float dpp_add_bcast31(float v) {   // rows 2,3 += lane 31
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
+}
+// Same sum, total left in lane 63 only (no readlane / broadcast).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0xb1>(v);
+  v = dpp_add<0x4e>(v);
+  v = dpp_add<0x124>(v);
+  v = dpp_add<0x128>(v);
+  v = dpp_add_bcast15(v);
+  v = dpp_add_bcast31(v);
+  return v;
+}
 // ---- 8 values x 64 lanes -> 8 totals in 18 VALU ops (instead of 8 x 6) ------
 // Halving tree on the gfx950 lane-swap instructions: each level folds the wave
 // in half AND packs two values into one register, so the work shrinks
@@ -97,7 +124,7 @@ __device__ __forceinline__ float tree_reduce8(const float v[8], int lane) {
   float u = (lane & 8) ? t2 : t1;
   u = dpp_add<0xb1>(u);                      // quad_perm [1,0,3,2]
   u = dpp_add<0x4e>(u);                      // quad_perm [2,3,0,1]
-  u = dpp_add<0x141>(u);                     // row_half_mirror: the other quad of the half
+  u = dpp_add_half_mirror(u);                // the other quad of the 8-lane half
   return u;
 }
 // value index held by (half h, row r) after tree_reduce8

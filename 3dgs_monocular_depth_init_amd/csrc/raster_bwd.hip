@@ -33,12 +33,10 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
                   const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows) {
-  __shared__ float4 sA[1][64];   // single buffer: the batch-end barriers already order reuse
-  __shared__ float4 sB[1][64];
-  // CH <= 3: {col2, quadrant mask}; CH 4,5: {col2, col3, col4, mask} (LDS per wave
-  // decides how many waves fit a CU: 9.7 KB -> 16 waves)
-  using CT = typename std::conditional<(CH <= 3), float2, float4>::type;
-  __shared__ CT sC[1][64];
+  // staged batch: [0] = {mx, my, ha, bb}, [1] = {hc, opacity, col0, col1},
+  // [2] = {col2, col3, col4, quadrant mask}. One array, so that the three wave-uniform
+  // reads of a Gaussian share one address register (base + j*16, offsets 0/1024/2048).
+  __shared__ float4 sRec[3][64];
   __shared__ int sId[1][64];
   __shared__ __attribute__((aligned(16))) float sG[64][GSR_GRAD_ROW];  // batch gradient rows
 
@@ -52,36 +50,40 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   const int lx = lane & 7, ly = lane >> 3;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
 
-  const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
-  if (e <= s) return;
-  // which field of a gradient row this lane stores after tree_reduce8 (-1: none).
-  // tree values: 0,1 = first moments (slots MEAN2D), 2..4 = conic, 5..7 = colours 0..2
-  int tree_field = -1;
+  // Which field of a gradient row this lane stores after the reductions (-1: none):
+  // lanes with (lane & 7) == 0 hold one tree_reduce8 total each -- tree values 0,1 = first
+  // moments (slots MEAN2D), 2..4 = conic, 5..7 = colours 0..2; lane 63 holds the wave sum
+  // of v_sigma (slot OPAC, scaled by -1/opacity at the flush); lane 1 raises the row's
+  // "touched" flag (slot 15). One predicated ds_write per Gaussian stores all of them.
+  int wfield = -1;
   if ((lane & 7) == 0) {
     const int ti = tree8_index(lane);
-    tree_field = (ti < 2) ? GSR_GR_MEAN2D + ti
-                 : (ti < 5) ? GSR_GR_CONIC + (ti - 2)
-                 : ((ti - 5) < CH ? GSR_GR_COLOR + (ti - 5) : -1);
+    wfield = (ti < 2) ? GSR_GR_MEAN2D + ti
+             : (ti < 5) ? GSR_GR_CONIC + (ti - 2)
+             : ((ti - 5) < CH ? GSR_GR_COLOR + (ti - 5) : -1);
   }
+  if (lane == 63) wfield = GSR_GR_OPAC;
+  if (lane == 1) wfield = 15;
 
-  // Kq = T_final * (v_alpha_out - <background, v_out>): the per-pixel constant of v_alpha
-  float px[4], py[2], T[4], Kq[4], buf_c[4][CH], vout[4][CH];
+  // R = T_final*(v_alpha_out - <background, v_out>) - <buf, v_out>, where buf is the colour
+  // accumulated behind the current Gaussian: only its dot product with v_out is ever
+  // needed, so one scalar per pixel replaces the CH-vector
+  float px[4], py[2], T[4], R[4], vout[4][CH];
   int last[4], qmax[4];
   py[0] = (float)(ty0 + ly) + 0.5f;
   py[1] = py[0] + 8.0f;
-  int max_last = -1;
+  const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
+  if (e <= s) return;
+  int max_last = -1, my_min_last = 0x7fffffff;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
     px[q] = (float)x + 0.5f;
     last[q] = -1;
     T[q] = 1.f;
-    Kq[q] = 0.f;
+    R[q] = 0.f;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      vout[q][k] = 0.f;
-      buf_c[q][k] = 0.f;
-    }
+    for (int k = 0; k < CH; ++k) vout[q][k] = 0.f;
     if (x < width && y < height) {
       const int64_t pix = ((int64_t)cam * height + y) * width + x;
       last[q] = last_ids[pix];
@@ -93,68 +95,81 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
 #pragma unroll
         for (int k = 0; k < CH; ++k) kk -= backgrounds[cam * CH + k] * vout[q][k];
       }
-      Kq[q] = T[q] * kk;
+      R[q] = T[q] * kk;
     }
     qmax[q] = __builtin_amdgcn_readfirstlane(wave_max_i32(last[q]));
     max_last = max(max_last, qmax[q]);
+    // a pixel outside the image or one nothing was blended into takes no part: park it
+    // (sigma -> huge, alpha -> 0 for every Gaussian) so that it never holds back the
+    // fast path below
+    if (last[q] < s) {
+      px[q] = PIX_DONE;
+      last[q] = 0x7fffffff;
+    }
+    my_min_last = min(my_min_last, last[q]);
   }
   if (max_last < s) return;  // nothing was blended into this tile (wave-uniform)
   const int start = min(max_last, e - 1);
+  // every pixel of the tile is active for list positions <= min_last: batches entirely
+  // below it need neither the per-pixel "idx <= last" test nor the per-quadrant one
+  const int min_last = -__builtin_amdgcn_readfirstlane(wave_max_i32(-my_min_last));
 
   // lane l of a batch stages Gaussian (batch_end - l): j = 0 is the LAST one.
+  // Software pipeline: ids two batches ahead, record rows one batch ahead (in flight
+  // during the loop over the current batch), LDS image built after the loop.
+  RawRec<CH> raw;
   TileRec<CH> rec;
-  int rId = 0;
-  if (start - lane >= s) {
-    rId = flatten_ids[start - lane];
-    stage_gauss<CH>(rId, records, (float)tx0, (float)ty0, rec);
-  }
+  // (loads are unconditional with clamped indices: a predicated load would merge old and
+  // new register values, and the copies that merge needs wait for the load right away)
+  int rId = flatten_ids[max(start - lane, s)];
+  load_raw<CH>(rId, records, raw);
+  int id_next = flatten_ids[max(start - 64 - lane, s)];
 
   constexpr int buf = 0;
   for (int batch_end = start; batch_end >= s; batch_end -= 64) {
     const int n = min(64, batch_end - s + 1);
+    bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp (no gradient there)
     if (lane < n) {
-      sA[buf][lane] = rec.a;
-      sB[buf][lane] = rec.b;
-      if constexpr (CH <= 3) sC[buf][lane] = make_float2(rec.c.x, rec.c.w);
-      else sC[buf][lane] = rec.c;
+      make_rec<CH>(raw, (float)tx0, (float)ty0, rec);
+      can_clamp = rec.b.y > gs::ALPHA_MAX;
+      sRec[0][lane] = rec.a;
+      sRec[1][lane] = rec.b;
+      sRec[2][lane] = rec.c;
       sId[buf][lane] = rId;
     }
     sG[lane][15] = 0.f;   // "row touched" flag of Gaussian `lane` of this batch
     __syncthreads();
-    const int nb = batch_end - 64;
-    if (nb - lane >= s) {
-      rId = flatten_ids[nb - lane];
-      stage_gauss<CH>(rId, records, (float)tx0, (float)ty0, rec);
-    }
+    rId = id_next;
+    load_raw<CH>(rId, records, raw);
+    id_next = flatten_ids[max(batch_end - 128 - lane, s)];
 
-    for (int j = 0; j < n; ++j) {
-      const float4 Ac = sA[buf][j], Bc = sB[buf][j];
-      float4 Cc;
-      if constexpr (CH <= 3) {
-        const float2 c2 = sC[buf][j];
-        Cc = make_float4(c2.x, 0.f, 0.f, c2.y);
-      } else {
-        Cc = sC[buf][j];
-      }
+    // One Gaussian against the tile. FAST (wave-uniform, decided per batch): every pixel
+    // is active and no opacity of the batch exceeds the alpha clamp, so the tests against
+    // last[] / qmax[] and the clamp handling are compiled out.
+    const bool fast_batch = (batch_end <= min_last) && !__any(can_clamp);
+    auto composite = [&](auto fast_tag, int j) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(sRec[2][j].w));
       const int idx = batch_end - j;
-      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(Cc.w));
+      if (!FAST) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (idx > qmax[q]) qm &= ~(1u << q);   // scalar: no pixel of q blended this far down
-      if (qm == 0) continue;
+        for (int q = 0; q < 4; ++q)
+          if (idx > qmax[q]) qm &= ~(1u << q);   // scalar: no pixel of q blended this far down
+      }
+      if (qm == 0) return;
+      const float4 Ac = sRec[0][j], Bc = sRec[1][j];
       float col[CH];
       col[0] = Bc.z;
       if (CH > 1) col[1] = Bc.w;
-      if (CH > 2) col[2] = Cc.x;
-      if (CH > 3) col[3] = Cc.y;
-      if (CH > 4) col[4] = Cc.z;
+      if (CH > 2) col[2] = sRec[2][j].x;
+      if (CH > 3) col[3] = sRec[2][j].y;
+      if (CH > 4) col[4] = sRec[2][j].z;
       const float opac = Bc.y;
       // conic in natural units for the gradient formulas: a = 2*ha/log2e etc.
       const float ca = Ac.z * (2.0f / LOG2E), cb = Ac.w * (1.0f / LOG2E), cc = Bc.x * (2.0f / LOG2E);
 
-      float g_xy[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_op = 0.f, g_col[CH];
+      float g_xy[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_vs = 0.f, g_col[CH];
       float g_abs[2] = {0.f, 0.f};
-      bool any_valid = false;
 #pragma unroll
       for (int k = 0; k < CH; ++k) g_col[k] = 0.f;
 #pragma unroll
@@ -163,27 +178,33 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           const float dx = Ac.x - px[q], dy = Ac.y - py[q >> 1];
           const float sg = sigma_l2(Ac.z, Ac.w, Bc.x, dx, dy);
           const float vis = __builtin_amdgcn_exp2f(-sg);
-          const float alpha = fminf(gs::ALPHA_MAX, opac * vis);
-          const bool valid = (idx <= last[q]) && (sg >= 0.f) && (alpha >= gs::ALPHA_THRESHOLD);
-          any_valid |= valid;
-          const float a = valid ? alpha : 0.f;
+          const float ov = opac * vis;
+          // valid <=> sigma >= 0 and alpha = min(0.999, ov) >= 1/255 (<=> ov >= 1/255):
+          // sigma's sign bit is OR-ed into ov, so one compare covers both
+          const float ovs = __uint_as_float(__float_as_uint(ov) | (__float_as_uint(sg) & 0x80000000u));
+          bool valid = ovs >= gs::ALPHA_THRESHOLD;
+          if (!FAST) valid = valid && (idx <= last[q]);
+          const float ovv = valid ? ov : 0.f;
+          // FAST: opacity <= 0.999 and exp2(-sigma) <= 1, so the clamp cannot bind
+          const float a = FAST ? ovv : fminf(gs::ALPHA_MAX, ovv);
           const float ra = __builtin_amdgcn_rcpf(1.0f - a);
           T[q] *= ra;
           const float fac = a * T[q];
-          float v_alpha = Kq[q] * ra;
+          float D = col[0] * vout[q][0];      // <colour, v_out>
 #pragma unroll
-          for (int k = 0; k < CH; ++k) {
-            g_col[k] = fmaf(fac, vout[q][k], g_col[k]);
-            v_alpha = fmaf(col[k] * T[q] - buf_c[q][k] * ra, vout[q][k], v_alpha);
-            buf_c[q][k] = fmaf(col[k], fac, buf_c[q][k]);
-          }
-          const float ov = opac * vis;
-          const float va = (valid && ov <= gs::ALPHA_MAX) ? v_alpha : 0.f;
-          const float v_sigma = -ov * va;
+          for (int k = 1; k < CH; ++k) D = fmaf(col[k], vout[q][k], D);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) g_col[k] = fmaf(fac, vout[q][k], g_col[k]);
+          // v_alpha = sum_k (col_k*T - buf_k/(1-a)) * v_out_k + T_final/(1-a) * (...)
+          const float v_alpha = fmaf(T[q], D, R[q] * ra);
+          R[q] = fmaf(-fac, D, R[q]);         // buf += col*fac  =>  <buf, v_out> += fac*D
+          // no gradient through a clamped alpha; ovv = 0 already silences an invalid pair
+          const float va = (FAST || ovv <= gs::ALPHA_MAX) ? v_alpha : 0.f;
+          const float v_sigma = -ovv * va;
           const float tdx = v_sigma * dx, tdy = v_sigma * dy;
-          g_con[0] = fmaf(0.5f * tdx, dx, g_con[0]);
-          g_con[1] = fmaf(tdx, dy, g_con[1]);
-          g_con[2] = fmaf(0.5f * tdy, dy, g_con[2]);
+          g_con[0] = fmaf(tdx, dx, g_con[0]);   // second moments; the 1/2 of v_conic.a / .c
+          g_con[1] = fmaf(tdx, dy, g_con[1]);   // is applied at the flush
+          g_con[2] = fmaf(tdy, dy, g_con[2]);
           // v_xy = conic * (sum v_sigma*dx, sum v_sigma*dy): only the two first
           // moments are summed per pixel, the 2x2 product is applied once after
           // the reduction (absgrad needs the per-pixel value).
@@ -193,24 +214,23 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
             g_abs[0] += fabsf(fmaf(ca, tdx, cb * tdy));
             g_abs[1] += fabsf(fmaf(cb, tdx, cc * tdy));
           }
-          g_op = fmaf(vis, va, g_op);
+          // v_opacity = sum vis*va = -(sum v_sigma) / opacity: the zeroth moment is
+          // summed, the division happens once at the flush
+          g_vs += v_sigma;
         }
       }
-      if (!__any(any_valid)) continue;  // wave-uniform skip
-      // 8 of the sums go through the lane-swap halving tree (18 VALU for all 8),
-      // the rest through plain wave sums; writer lanes store straight into the
-      // batch's 64-byte LDS row.
+      // 8 of the sums go through the lane-swap halving tree (18 VALU for all 8), the
+      // zeroth moment through a plain wave sum that ends in lane 63; the writer lanes
+      // (wfield) store everything with one predicated ds_write into the 64-byte LDS row.
       {
         const float tv[8] = {g_xy[0], g_xy[1], g_con[0], g_con[1], g_con[2], g_col[0],
                              (CH > 1) ? g_col[1] : 0.f, (CH > 2) ? g_col[2] : 0.f};
-        const float u = tree_reduce8(tv, lane);
-        const float r_o = wave_sum(g_op);
+        float u = tree_reduce8(tv, lane);
+        const float r_s = wave_sum_lane63(g_vs);
+        u = (lane == 63) ? r_s : u;
+        u = (lane == 1) ? 1.0f : u;
         float *row = &sG[j][0];
-        if (tree_field >= 0) row[tree_field] = u;      // 8 writer lanes
-        if (lane == 0) {
-          row[GSR_GR_OPAC] = r_o;
-          row[15] = 1.0f;                              // "row touched" flag
-        }
+        if (wfield >= 0) row[wfield] = u;
         if (CH > 3) {
           const float r3 = wave_sum(g_col[3]);
           if (lane == 0) row[GSR_GR_COLOR + 3] = r3;
@@ -227,6 +247,11 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           }
         }
       }
+    };
+    if (fast_batch) {
+      for (int j = 0; j < n; ++j) composite(std::true_type{}, j);
+    } else {
+      for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
     }
     __syncthreads();
     // flush: 4 Gaussians per wave instruction, 16 lanes = one 64-byte row
@@ -239,13 +264,15 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
         const int g = sId[buf][j];
         float val = sG[j][f];
         if (f < 2) {   // v_xy = conic * (first moments): row holds (m_x, m_y)
-          const float4 Aj = sA[buf][j];
-          const float4 Bj = sB[buf][j];
+          const float4 Aj = sRec[0][j];
+          const float4 Bj = sRec[1][j];
           const float ca = Aj.z * (2.0f / LOG2E), cb = Aj.w * (1.0f / LOG2E),
                       cc = Bj.x * (2.0f / LOG2E);
           const float mx_ = sG[j][0], my_ = sG[j][1];
           val = (f == 0) ? fmaf(ca, mx_, cb * my_) : fmaf(cb, mx_, cc * my_);
         }
+        if (f == GSR_GR_OPAC) val = -val / sRec[1][j].y;   // row holds sum v_sigma
+        if (f == GSR_GR_CONIC || f == GSR_GR_CONIC + 2) val *= 0.5f;
         atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, val);
       }
     }
@@ -264,6 +291,7 @@ __global__ void debug_tree_reduce8_kernel(const float *__restrict__ in, float *_
   out[lane] = tree_reduce8(v, lane);
   idx_out[lane] = tree8_index(lane);
   out[64 + lane] = wave_sum(v[0]);
+  out[128 + lane] = wave_sum_lane63(v[1]);   // only lane 63 is meaningful
 }
 
 template <int CH>

@@ -53,14 +53,27 @@ __device__ __forceinline__ float min_sigma_rect(float a, float b, float c, float
 // written by gsr_project_fwd (or gsr_pack_records for caller-supplied colours).
 constexpr int REC_FLOATS = 16;
 
-// Gather Gaussian g's record and build its LDS image for the tile at (tx0, ty0).
+// The gather and the LDS image are split so that the kernels can software-pipeline:
+// the loads of batch b+1 are issued before the compositing loop of batch b and only
+// consumed (make_rec) after it, so their latency is covered by the wave's own work.
 template <int CH>
-__device__ __forceinline__ void stage_gauss(int g, const float *__restrict__ records, float tx0,
-                                            float ty0, TileRec<CH> &r) {
+struct RawRec {
+  float4 r0, r1, r2;
+};
+
+template <int CH>
+__device__ __forceinline__ void load_raw(int g, const float *__restrict__ records, RawRec<CH> &w) {
   const float4 *row = reinterpret_cast<const float4 *>(records + (int64_t)g * REC_FLOATS);
-  const float4 r0 = row[0], r1 = row[1];
-  float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (CH > 2) r2 = row[2];
+  w.r0 = row[0];
+  w.r1 = row[1];
+  if (CH > 3) w.r2 = row[2];
+  else if (CH > 2) w.r2.x = records[(int64_t)g * REC_FLOATS + 8];
+}
+
+// Build the LDS image of a gathered record for the tile at (tx0, ty0).
+template <int CH>
+__device__ __forceinline__ void make_rec(const RawRec<CH> &w, float tx0, float ty0, TileRec<CH> &r) {
+  const float4 r0 = w.r0, r1 = w.r1;
   const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
   // alpha >= 1/255  <=>  sigma <= ln(255*op); small margin keeps the test conservative
   const float tau = logf(op * 255.0f);
@@ -74,7 +87,8 @@ __device__ __forceinline__ void stage_gauss(int g, const float *__restrict__ rec
   }
   r.a = make_float4(r0.x, r0.y, 0.5f * a * LOG2E, b * LOG2E);
   r.b = make_float4(0.5f * c * LOG2E, op, r1.z, r1.w);
-  r.c = make_float4(r2.x, r2.y, r2.z, __int_as_float(qmask));
+  r.c = make_float4(CH > 2 ? w.r2.x : 0.f, CH > 3 ? w.r2.y : 0.f, CH > 4 ? w.r2.z : 0.f,
+                    __int_as_float(qmask));
 }
 
 }  // namespace gsr

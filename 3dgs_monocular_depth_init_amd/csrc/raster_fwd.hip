@@ -59,9 +59,18 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   }
 
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
+  // software pipeline: ids two batches ahead, record rows one batch ahead (in flight
+  // during the compositing loop), LDS image built after the loop
+  RawRec<CH> raw;
   TileRec<CH> rec;
-  if (s + lane < e)
-    stage_gauss<CH>(flatten_ids[s + lane], records, (float)tx0, (float)ty0, rec);
+  // (loads are unconditional with clamped indices: a predicated load would merge old and
+  // new register values, and the copies that merge needs wait for the load right away)
+  if (e <= s) {
+    raw.r0 = raw.r1 = raw.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    load_raw<CH>(flatten_ids[min(s + lane, e - 1)], records, raw);
+  }
+  int id_next = (e > s) ? flatten_ids[min(s + 64 + lane, e - 1)] : 0;
   int buf = 0;
   unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
   for (int base = s; base < e; base += 64) {
@@ -72,15 +81,15 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     if (live == 0) break;
     const int n = min(64, e - base);
     if (lane < n) {
+      make_rec<CH>(raw, (float)tx0, (float)ty0, rec);
       sA[buf][lane] = rec.a;
       sB[buf][lane] = rec.b;
       if constexpr (CH <= 3) sC[buf][lane] = make_float2(rec.c.x, rec.c.w);
       else sC[buf][lane] = rec.c;
     }
     __syncthreads();
-    const int nb = base + 64;
-    if (nb + lane < e)
-      stage_gauss<CH>(flatten_ids[nb + lane], records, (float)tx0, (float)ty0, rec);
+    load_raw<CH>(id_next, records, raw);
+    id_next = flatten_ids[min(base + 128 + lane, e - 1)];
     for (int j = 0; j < n; ++j) {
       const float4 Ac = sA[buf][j], Bc = sB[buf][j];
       float4 Cc;

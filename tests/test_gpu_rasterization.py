@@ -244,7 +244,7 @@ def test_tree_reduce8(R):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(8, 64, generator=g, dtype=torch.float32)
     xin = x.cuda().contiguous()
-    out = torch.empty(128, device="cuda")
+    out = torch.empty(192, device="cuda")
     idx = torch.empty(64, dtype=torch.int32, device="cuda")
     lib.call("gsr_debug_tree_reduce8", xin.data_ptr(), out.data_ptr(), idx.data_ptr(),
              torch.cuda.current_stream().cuda_stream)
@@ -253,7 +253,8 @@ def test_tree_reduce8(R):
     idx = idx.cpu().long()
     assert sorted(set(idx.tolist())) == list(range(8))
     assert torch.allclose(out[:64].cpu().double(), tot[idx], atol=1e-4)
-    assert torch.allclose(out[64:].cpu().double(), tot[0].expand(64), atol=1e-4)
+    assert torch.allclose(out[64:128].cpu().double(), tot[0].expand(64), atol=1e-4)
+    assert float(out[191]) == pytest.approx(float(tot[1]), abs=1e-4)      # wave_sum_lane63
 
 
 def test_bucketed_and_atomic_tile_lists_agree(R):
