@@ -173,16 +173,22 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
 #pragma unroll
       for (int k = 0; k < CH; ++k) g_col[k] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (qm & (1u << q)) {   // scalar branch
-          const float dx = Ac.x - px[q], dy = Ac.y - py[q >> 1];
-          const float sg = sigma_l2(Ac.z, Ac.w, Bc.x, dx, dy);
+      for (int r = 0; r < 2; ++r) {
+       if (qm & (3u << (2 * r))) {   // scalar: this row of quadrants is touched
+        const float dy = Ac.y - py[r];
+        float Br, Cr;
+        sigma_row_terms(Ac.w, Bc.x, dy, Br, Cr);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+         const int q = 2 * r + h;
+         if (qm & (1u << q)) {   // scalar branch
+          const float dx = Ac.x - px[q];
+          const float sg = sigma_l2(Ac.z, dx, Br, Cr);
           const float vis = __builtin_amdgcn_exp2f(-sg);
           const float ov = opac * vis;
           // valid <=> sigma >= 0 and alpha = min(0.999, ov) >= 1/255 (<=> ov >= 1/255):
           // sigma's sign bit is OR-ed into ov, so one compare covers both
-          const float ovs = __uint_as_float(__float_as_uint(ov) | (__float_as_uint(sg) & 0x80000000u));
-          bool valid = ovs >= gs::ALPHA_THRESHOLD;
+          bool valid = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
           if (!FAST) valid = valid && (idx <= last[q]);
           const float ovv = valid ? ov : 0.f;
           // FAST: opacity <= 0.999 and exp2(-sigma) <= 1, so the clamp cannot bind
@@ -217,7 +223,9 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           // v_opacity = sum vis*va = -(sum v_sigma) / opacity: the zeroth moment is
           // summed, the division happens once at the flush
           g_vs += v_sigma;
+         }
         }
+       }
       }
       // 8 of the sums go through the lane-swap halving tree (18 VALU for all 8), the
       // zeroth moment through a plain wave sum that ends in lane 63; the writer lanes

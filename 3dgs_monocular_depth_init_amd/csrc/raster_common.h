@@ -25,11 +25,21 @@ struct TileRec {      // LDS image of one staged Gaussian
   float4 c;           // col2, col3, col4, quadrant mask (int bits)
 };
 
-// sigma' = log2(e) * sigma, evaluated identically in forward and backward.
-__device__ __forceinline__ float sigma_l2(float ha, float bb, float hc, float dx, float dy) {
-  float s = (ha * dx) * dx;
-  s = fmaf(hc * dy, dy, s);
-  return fmaf(bb * dx, dy, s);
+// sigma' = log2(e) * sigma = ha*dx^2 + bb*dx*dy + hc*dy^2, evaluated identically in
+// forward and backward as dx*(ha*dx + B) + C with the row terms B = bb*dy, C = hc*dy*dy:
+// the two quadrants of a row share dy, so B and C cost 3 VALU per (Gaussian, row) and
+// sigma 2 per pixel (the kernels issue one VALU instruction per 4 cycles per SIMD and
+// are bound by exactly that, so instruction counts are what the layout is chosen for).
+__device__ __forceinline__ void sigma_row_terms(float bb, float hc, float dy, float &B, float &C) {
+  B = bb * dy;
+  C = (hc * dy) * dy;
+}
+__device__ __forceinline__ float sigma_l2(float ha, float dx, float B, float C) {
+  return fmaf(dx, fmaf(ha, dx, B), C);
+}
+// ov with sigma's sign bit OR-ed in: (result >= threshold) <=> (sigma >= 0 and ov >= threshold)
+__device__ __forceinline__ float with_sign_of(float ov, float sigma) {
+  return __uint_as_float(__float_as_uint(ov) | (__float_as_uint(sigma) & 0x80000000u));
 }
 
 // min over the rectangle of pixel centres [x0,x1]x[y0,y1] of
