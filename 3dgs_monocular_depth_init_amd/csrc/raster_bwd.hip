@@ -49,6 +49,10 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
+  // tile origin as floats held in SCALAR registers (wave-uniform; a VGPR copy would be
+  // hoisted out of the loops and cost the compositing loops registers)
+  const float ftx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)tx0)));
+  const float fty0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)ty0)));
 
   // Which field of a gradient row this lane stores after the reductions (-1: none):
   // lanes with (lane & 7) == 0 hold one tree_reduce8 total each -- tree values 0,1 = first
@@ -130,7 +134,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     const int n = min(64, batch_end - s + 1);
     bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp (no gradient there)
     if (lane < n) {
-      make_rec<CH>(raw, (float)tx0, (float)ty0, rec);
+      make_rec<CH>(raw, ftx0, fty0, rec);
       can_clamp = rec.b.y > gs::ALPHA_MAX;
       sRec[0][lane] = rec.a;
       sRec[1][lane] = rec.b;

@@ -46,7 +46,10 @@ __device__ __forceinline__ float with_sign_of(float ov, float sigma) {
 // sigma(d) = 0.5*(a dx^2 + c dy^2) + b dx dy, d = mean - pixel.
 __device__ __forceinline__ float min_sigma_rect(float a, float b, float c, float mx, float my,
                                                 float x0, float x1, float y0, float y1) {
-  const float dxlo = mx - x1, dxhi = mx - x0, dylo = my - y1, dyhi = my - y0;
+  // (x1 - x0 and y1 - y0 are compile-time constants at the call sites: written so that the
+  // wave-uniform x0 / y0 are each used once and can stay in scalar registers)
+  const float dxhi = mx - x0, dyhi = my - y0;
+  const float dxlo = dxhi - (x1 - x0), dylo = dyhi - (y1 - y0);
   if (dxlo <= 0.f && dxhi >= 0.f && dylo <= 0.f && dyhi >= 0.f) return 0.f;
   auto sig = [&](float dx, float dy) { return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy; };
   const float ic = 1.0f / c, ia = 1.0f / a;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void make_rec(const RawRec<CH> &w, float tx0, float t
   int qmask = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float x0 = tx0 + 8.f * (float)(q & 1) + 0.5f, y0 = ty0 + 8.f * (float)(q >> 1) + 0.5f;
+    const float x0 = tx0 + (8.f * (float)(q & 1) + 0.5f), y0 = ty0 + (8.f * (float)(q >> 1) + 0.5f);
     const float ms = min_sigma_rect(a, b, c, r0.x, r0.y, x0, x0 + 7.f, y0, y0 + 7.f);
     qmask |= (ms <= tau_m) ? (1 << q) : 0;
   }

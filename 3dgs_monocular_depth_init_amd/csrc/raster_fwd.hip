@@ -39,6 +39,10 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
+  // tile origin as floats held in SCALAR registers (wave-uniform; a VGPR copy would be
+  // hoisted out of the loops and cost the compositing loops registers)
+  const float ftx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)tx0)));
+  const float fty0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)ty0)));
 
   // pixel q of this lane: (tx0 + 8*(q&1) + lx, ty0 + 8*(q>>1) + ly)
   float px[4], py[2], T[4], acc[4][CH];
@@ -84,7 +88,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     const int n = min(64, e - base);
     bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp
     if (lane < n) {
-      make_rec<CH>(raw, (float)tx0, (float)ty0, rec);
+      make_rec<CH>(raw, ftx0, fty0, rec);
       can_clamp = rec.b.y > gs::ALPHA_MAX;
       sRec[buf][0][lane] = rec.a;
       sRec[buf][1][lane] = rec.b;

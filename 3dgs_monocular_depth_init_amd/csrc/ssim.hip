@@ -200,18 +200,28 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
 __global__ void __launch_bounds__(256)
 l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
               double *__restrict__ sum) {
-  // fp32 partial per thread (a few dozen terms of magnitude <= 1), fp64 across threads
+  // fp32 partial per thread (a few dozen terms of magnitude <= 1), fp64 across threads.
+  // Few, fat workgroups: the kernel ends with one same-address fp64 atomic per workgroup
+  // and those serialise at the memory side (2048 of them cost more than the 50 MB read),
+  // so each thread keeps 4 independent 16-byte load pairs in flight instead.
   float part = 0.f;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-    if (i + 3 < n) {
-      const float4 x = *reinterpret_cast<const float4 *>(a + i);
-      const float4 y = *reinterpret_cast<const float4 *>(b + i);
-      part += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
-    } else {
-      for (int64_t k = i; k < n; ++k) part += fabsf(a[k] - b[k]);
-    }
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  const float4 *a4 = reinterpret_cast<const float4 *>(a);
+  const float4 *b4 = reinterpret_cast<const float4 *>(b);
+  auto l1 = [](const float4 &x, const float4 &y) {
+    return (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+  };
+  int64_t i = tid;
+  for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
+    const float4 x0 = a4[i], x1 = a4[i + nthreads], x2 = a4[i + 2 * nthreads], x3 = a4[i + 3 * nthreads];
+    const float4 y0 = b4[i], y1 = b4[i + nthreads], y2 = b4[i + 2 * nthreads], y3 = b4[i + 3 * nthreads];
+    part += (l1(x0, y0) + l1(x1, y1)) + (l1(x2, y2) + l1(x3, y3));
   }
+  for (; i < n4; i += nthreads) part += l1(a4[i], b4[i]);
+  if (tid == 0)
+    for (int64_t k = n4 << 2; k < n; ++k) part += fabsf(a[k] - b[k]);
   __shared__ double red[4];
   double acc = wave_sum_f64((double)part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -243,7 +253,7 @@ extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *sum
   GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "l1_fwd: buffers must be 16-byte aligned");
   GSR_CHECK_HIP(hipMemsetAsync(sum, 0, sizeof(double), (hipStream_t)stream));
   if (n == 0) return GSR_OK;
-  int blocks = (int)(gsr::ceil_div64(n, 1024) < 2048 ? gsr::ceil_div64(n, 1024) : 2048);
+  int blocks = (int)(gsr::ceil_div64(n, 4096) < 512 ? gsr::ceil_div64(n, 4096) : 512);
   hipLaunchKernelGGL(gsr::l1_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
                      sum);
   GSR_CHECK_LAUNCH("l1_fwd");
