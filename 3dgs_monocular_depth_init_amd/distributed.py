@@ -30,10 +30,17 @@ class GradSync:
     Fallback (grads that are not arena views, e.g. CPU/gloo tests, extra
     autograd consumers): one async all-reduce per tensor, SH first.
     Gradients are summed (the loss of a W-view batch is the sum of per-view
-    losses, as with the reference's batch dimension) unless `average=True`."""
+    losses, as with the reference's batch dimension) unless `average=True`.
+
+    Pipelining with the optimizer: after `attach(fused_adam)` the arena is
+    reduced as `chunks` asynchronous all-reduces (RCCL runs them in order on
+    its own stream) and `FusedAdam.step()` waits chunk by chunk, so the Adam
+    update of chunk k overlaps the all-reduce of chunk k+1 (Adam is
+    element-wise, so any flat range of the arena can be stepped on its own).
+    `finish()` waits for whatever nobody consumed."""
 
     def __init__(self, splats, world_size: int, average: bool = False, group=None,
-                 use_arena: bool = True, force: bool = False):
+                 use_arena: bool = True, force: bool = False, chunks: int = 4):
         self.splats = splats
         self.world = world_size
         self.average = average
@@ -41,7 +48,37 @@ class GradSync:
         self.arena = None
         self.use_arena = use_arena
         self.force = force              # issue the collective even at world_size 1 (rehearsal)
+        self.chunks = max(1, int(chunks))
+        self._consumer = None           # FusedAdam that consumes pending chunks
+        self._pending = []              # [(work, start, end)] in arena elements, issue order
         self._maybe_build_arena()
+
+    def attach(self, fused_adam) -> None:
+        """Let `fused_adam.step()` consume the chunked all-reduce as it completes."""
+        self._consumer = fused_adam
+        fused_adam.grad_sync = self
+
+    def chunk_bounds(self):
+        """Equal flat ranges of the arena, boundaries on 16-byte multiples."""
+        n = self.arena.flat.numel()
+        k = self.chunks
+        step = (n // k + 3) // 4 * 4
+        out, a = [], 0
+        while a < n:
+            b = min(n, a + step) if len(out) < k - 1 else n
+            out.append((a, b))
+            a = b
+        return out
+
+    def take_pending(self):
+        p, self._pending = self._pending, []
+        return p
+
+    def finish(self) -> None:
+        for work, a, b in self.take_pending():
+            work.wait()
+            if self.average:
+                self.arena.flat[a:b].div_(self.world)
 
     def _maybe_build_arena(self) -> None:
         if not self.use_arena:
@@ -64,9 +101,17 @@ class GradSync:
         names = [n for n in PARAM_ORDER if n in self.splats]
         if self.arena is not None and all(self.arena.owns(n, self.splats[n].grad) for n in names) \
                 and len(names) == len(self.arena.offsets):
-            dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                self.arena.flat.div_(self.world)
+            if self._consumer is not None and self.chunks > 1:
+                self.finish()
+                flat = self.arena.flat
+                for a, b in self.chunk_bounds():
+                    work = dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                           async_op=True)
+                    self._pending.append((work, a, b))
+            else:
+                dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.average:
+                    self.arena.flat.div_(self.world)
         else:
             works = []
             for name in names:

@@ -31,6 +31,7 @@ class FusedAdam:
         if len(optimizers) > 8:
             raise ValueError("at most 8 tensors per fused launch")
         self.optimizers = optimizers
+        self.grad_sync = None           # distributed.GradSync.attach() sets this
 
     # dict-like access so existing code (`optimizers["means"]`, `.values()`) keeps working
     def __getitem__(self, k):
@@ -45,11 +46,12 @@ class FusedAdam:
     def items(self):
         return self.optimizers.items()
 
-    @torch.no_grad()
-    def step(self) -> None:
-        ps, gs, ms, vs, numel, ss, bc2 = [], [], [], [], [], [], []
+    def _prepare(self):
+        """Per-tensor launch parameters; creates missing state and advances `step`.
+        Returns ([(name, p, g, exp_avg, exp_avg_sq, step_size, bc2_sqrt)], beta1, beta2, eps)."""
+        items = []
         beta1 = beta2 = eps = None
-        for opt in self.optimizers.values():
+        for name, opt in self.optimizers.items():
             grp = opt.param_groups[0]
             p = grp["params"][0]
             if p.grad is None:
@@ -69,18 +71,67 @@ class FusedAdam:
                 beta1, beta2, eps = float(b1), float(b2), float(grp["eps"])
             elif (float(b1), float(b2), float(grp["eps"])) != (beta1, beta2, eps):
                 raise ValueError("FusedAdam: all parameters must share betas and eps")
-            ps.append(p.data_ptr()); gs.append(g.data_ptr())
-            ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
-            numel.append(p.numel())
-            ss.append(float(grp["lr"]) / (1.0 - beta1 ** t))
-            bc2.append((1.0 - beta2 ** t) ** 0.5)
-        n = len(ps)
+            items.append((name, p, g, st["exp_avg"], st["exp_avg_sq"],
+                          float(grp["lr"]) / (1.0 - beta1 ** t), (1.0 - beta2 ** t) ** 0.5))
+        return items, beta1, beta2, eps
+
+    @staticmethod
+    def _launch(pieces, beta1, beta2, eps) -> None:
+        """pieces: [(p_ptr, g_ptr, m_ptr, v_ptr, numel, step_size, bc2_sqrt)], at most 8."""
+        n = len(pieces)
         if n == 0:
             return
         PA = C.c_void_p * n
-        call("gsr_adam_step", n, PA(*ps), PA(*gs), PA(*ms), PA(*vs), (C.c_int64 * n)(*numel),
-             (C.c_float * n)(*ss), (C.c_float * n)(*bc2), beta1, beta2, eps,
+        call("gsr_adam_step", n, PA(*[x[0] for x in pieces]), PA(*[x[1] for x in pieces]),
+             PA(*[x[2] for x in pieces]), PA(*[x[3] for x in pieces]),
+             (C.c_int64 * n)(*[x[4] for x in pieces]), (C.c_float * n)(*[x[5] for x in pieces]),
+             (C.c_float * n)(*[x[6] for x in pieces]), beta1, beta2, eps,
              torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def pieces_for_range(a: int, b: int, segments):
+        """Intersect the arena range [a, b) with parameter segments
+        [(key, arena_offset, numel)] -> [(key, start_in_param, count)]."""
+        out = []
+        for key, off, n in segments:
+            lo, hi = max(a, off), min(b, off + n)
+            if hi > lo:
+                out.append((key, lo - off, hi - lo))
+        return out
+
+    @torch.no_grad()
+    def step(self) -> None:
+        items, beta1, beta2, eps = self._prepare()
+        sync = self.grad_sync
+        pending = sync.take_pending() if sync is not None else []
+        if pending:
+            arena = sync.arena
+            by_name = {it[0]: it for it in items}
+            ok = arena is not None and all(
+                name in by_name and arena.owns(name, by_name[name][2]) for name in arena.offsets
+            ) and len(by_name) == len(arena.offsets)
+            if not ok:                       # grads are not the arena's views: plain path
+                for work, a, b in pending:
+                    work.wait()
+                    if sync.average:
+                        arena.flat[a:b].div_(sync.world)
+                pending = []
+            else:
+                segs = [(name, arena.offsets[name], by_name[name][1].numel()) for name in arena.offsets]
+                for work, a, b in pending:   # Adam on chunk k overlaps the all-reduce of k+1
+                    work.wait()
+                    if sync.average:
+                        arena.flat[a:b].div_(sync.world)
+                    pieces = []
+                    for name, start, cnt in self.pieces_for_range(a, b, segs):
+                        _, p, g, m, v, ss, bc2 = by_name[name]
+                        o = 4 * start
+                        pieces.append((p.data_ptr() + o, g.data_ptr() + o, m.data_ptr() + o,
+                                       v.data_ptr() + o, cnt, ss, bc2))
+                    self._launch(pieces, beta1, beta2, eps)
+                return
+        self._launch([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ss, bc2)
+                      for _, p, g, m, v, ss, bc2 in items], beta1, beta2, eps)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for opt in self.optimizers.values():

@@ -178,4 +178,6 @@ def train_step(
             for opt in optimizers.values():                              # runner.py:676-679
                 opt.step()
                 opt.zero_grad(set_to_none=True)
+    if grad_sync is not None and hasattr(grad_sync, "finish"):
+        grad_sync.finish()           # chunks no optimizer consumed (e.g. optimizers=None)
     return loss.detach(), info

@@ -166,6 +166,8 @@ def main():
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
     cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
     sync = distributed.GradSync(splats, world, force=use_dist) if use_dist else None
+    if sync is not None and not args.no_optimizer:
+        sync.attach(optimizers)      # Adam on chunk k overlaps the all-reduce of chunk k+1
     info_box = {}
 
     def step(k: int):

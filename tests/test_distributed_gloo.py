@@ -104,3 +104,30 @@ def test_lr_scaling_rule_matches_reference():
     assert opts["shN"].param_groups[0]["lr"] == pytest.approx(2.5e-3 / 20 * 2.0)
     assert set(splats.keys()) == {"means", "scales", "quats", "opacities", "sh0", "shN"}
     assert splats["sh0"].shape == (10, 1, 3) and splats["shN"].shape == (10, 15, 3)
+
+
+def test_chunk_to_parameter_pieces_cover_every_element_once():
+    """The pipelined optimizer steps arbitrary flat ranges of the gradient arena: the
+    range -> (parameter, offset, count) mapping must tile every parameter exactly."""
+    optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
+    N = 1237
+    numel = {"shN": 45 * N, "sh0": 3 * N, "means": 3 * N, "quats": 4 * N, "scales": 3 * N, "opacities": N}
+    segs, off = [], 0
+    for k, n in numel.items():                       # arena layout: 16-byte aligned segments
+        segs.append((k, off, n))
+        off += (n + 3) // 4 * 4
+    total = off
+    for chunks in (1, 3, 4, 7):
+        step = (total // chunks + 3) // 4 * 4
+        bounds, a = [], 0
+        while a < total:
+            b = min(total, a + step) if len(bounds) < chunks - 1 else total
+            bounds.append((a, b)); a = b
+        seen = {k: torch.zeros(n, dtype=torch.int32) for k, n in numel.items()}
+        for a, b in bounds:
+            pieces = optim.FusedAdam.pieces_for_range(a, b, segs)
+            assert len(pieces) <= 8
+            for k, start, cnt in pieces:
+                assert start % 4 == 0 and cnt > 0
+                seen[k][start:start + cnt] += 1
+        assert all(bool((v == 1).all()) for v in seen.values())
