@@ -4,6 +4,7 @@
 // gs_init_compare/runner.py:129-137, 676-679 (7 x 236 MB of HBM traffic at
 // 1M Gaussians: read p,g,m,v, write p,m,v -- streamed once, 16 B per lane).
 #include "common.h"
+#include "gs_math.h"
 
 namespace gsr {
 
@@ -110,7 +111,84 @@ __global__ void inverse4x4_kernel(int C, const float *__restrict__ in, float *__
   }
 }
 
+// ---- MCMC strategy (reference call site runner.py:649-658) ----
+// Relocation ("3D Gaussian Splatting as Markov Chain Monte Carlo", eq. 9): a Gaussian
+// that is to be represented by N copies gets opacity o' = 1 - (1 - o)^(1/N) and its
+// scales multiplied by o / sum_{i=1..N} sum_{k=0..i-1} C(i-1,k) (-1)^k o'^(k+1)/sqrt(k+1).
+__global__ void __launch_bounds__(256)
+relocation_kernel(int n, const float *__restrict__ opacities, const float *__restrict__ scales,
+                  const int32_t *__restrict__ ratios, const float *__restrict__ binoms, int n_max,
+                  float *__restrict__ new_opacities, float *__restrict__ new_scales) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int N = min(max(ratios[i], 1), n_max);
+  const float o = opacities[i];
+  const float no = 1.0f - powf(1.0f - o, 1.0f / (float)N);
+  float denom = 0.f;
+  for (int a = 1; a <= N; ++a) {
+    float pw = no, sgn = 1.f;                 // o'^(k+1), (-1)^k
+    for (int k = 0; k <= a - 1; ++k) {
+      denom += binoms[(a - 1) * n_max + k] * (sgn * rsqrtf((float)(k + 1)) * pw);
+      pw *= no;
+      sgn = -sgn;
+    }
+  }
+  const float coeff = o / denom;
+  new_opacities[i] = no;
+  new_scales[i * 3 + 0] = coeff * scales[i * 3 + 0];
+  new_scales[i * 3 + 1] = coeff * scales[i * 3 + 1];
+  new_scales[i * 3 + 2] = coeff * scales[i * 3 + 2];
+}
+
+// Position noise of the MCMC strategy, fused: means += Sigma * (noise * s(1 - sigmoid(op)) *
+// scaler), Sigma = R diag(exp(scales))^2 R^T, s(x) = 1/(1 + exp(-100 (x - 0.995))).
+// Replaces sigmoid, exp, quat->covariance, the gate, an einsum and the add (seven
+// passes over N) by one 68-byte-per-Gaussian pass.
+__global__ void __launch_bounds__(256)
+inject_noise_kernel(int N, float *__restrict__ means, const float *__restrict__ quats,
+                    const float *__restrict__ log_scales, const float *__restrict__ logit_opac,
+                    const float *__restrict__ noise, float scaler) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float op = 1.0f / (1.0f + expf(-logit_opac[i]));
+  const float gate = 1.0f / (1.0f + expf(-100.0f * ((1.0f - op) - 0.995f))) * scaler;
+  const float q[4] = {quats[i * 4], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
+  const float sc[3] = {expf(log_scales[i * 3]), expf(log_scales[i * 3 + 1]), expf(log_scales[i * 3 + 2])};
+  const gs::Mat3 cov = gs::quat_scale_to_covar(q, sc);
+  const float nz[3] = {noise[i * 3] * gate, noise[i * 3 + 1] * gate, noise[i * 3 + 2] * gate};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    means[i * 3 + r] += cov.m[r][0] * nz[0] + cov.m[r][1] * nz[1] + cov.m[r][2] * nz[2];
+}
+
 }  // namespace gsr
+
+extern "C" int gsr_relocation(int n, const float *opacities, const float *scales,
+                              const int32_t *ratios, const float *binoms, int n_max,
+                              float *new_opacities, float *new_scales, void *stream) {
+  GSR_REQUIRE(n >= 0 && n_max > 0, "relocation: bad sizes");
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(opacities && scales && ratios && binoms && new_opacities && new_scales,
+              "relocation: null pointer");
+  hipLaunchKernelGGL(gsr::relocation_kernel, dim3(gsr::ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, opacities, scales, ratios, binoms, n_max,
+                     new_opacities, new_scales);
+  GSR_CHECK_LAUNCH("relocation");
+  return GSR_OK;
+}
+
+extern "C" int gsr_inject_noise(int N, float *means, const float *quats, const float *log_scales,
+                                const float *logit_opacities, const float *noise, float scaler,
+                                void *stream) {
+  GSR_REQUIRE(N >= 0, "inject_noise: bad N");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(means && quats && log_scales && logit_opacities && noise, "inject_noise: null pointer");
+  hipLaunchKernelGGL(gsr::inject_noise_kernel, dim3(gsr::ceil_div(N, 256)), dim3(256), 0,
+                     (hipStream_t)stream, N, means, quats, log_scales, logit_opacities, noise,
+                     scaler);
+  GSR_CHECK_LAUNCH("inject_noise");
+  return GSR_OK;
+}
 
 extern "C" int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation,
                               void *stream) {

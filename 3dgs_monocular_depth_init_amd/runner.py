@@ -144,8 +144,10 @@ def train_step(
     cfg: RasterConfig = RasterConfig(),
     ssim_lambda: float = 0.0,
     grad_sync=None,          # callable run between backward and optimizer.step (all-reduce)
-    strategy=None,           # strategy.DefaultStrategy (runner.py:497-503, 639-647)
+    strategy=None,           # strategy.DefaultStrategy / MCMCStrategy (runner.py:497-503, 639-658)
     strategy_state=None,
+    opacity_reg: float = 0.0,   # runner.py:535-539 (0.01 in the "mcmc" preset, trainer.py:83-92)
+    scale_reg: float = 0.0,     # runner.py:540-545
 ) -> Tuple[Tensor, Dict]:
     """One iteration of Runner.train's body (runner.py:464-547, 676-689):
     SH-degree schedule, render, L1 (+ optional SSIM term), backward,
@@ -165,11 +167,20 @@ def train_step(
     else:
         from .losses import l1_loss
         loss = l1_loss(colors, pixels)                                  # runner.py:506
+    if opacity_reg > 0.0:                                                # runner.py:535-539
+        loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
+    if scale_reg > 0.0:                                                  # runner.py:540-545
+        loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
     loss.backward()                                                      # runner.py:547
     if grad_sync is not None:
         grad_sync()
-    if strategy is not None:                                             # runner.py:639-647
-        strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
+    if strategy is not None:                                             # runner.py:639-658
+        from .strategy import MCMCStrategy
+        if isinstance(strategy, MCMCStrategy):
+            means_lr = optimizers["means"].param_groups[0]["lr"]        # schedulers[0].get_last_lr()[0]
+            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, lr=means_lr)
+        else:
+            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
     if optimizers is not None:
         if hasattr(optimizers, "step"):                                  # FusedAdam: one launch
             optimizers.step()

@@ -252,3 +252,179 @@ class DefaultStrategy:
         if n_prune > 0:
             remove(params, optimizers, state, is_prune)
         return n_prune
+
+
+# ---------------------------------------------------------------------------------------
+# MCMC strategy ("3D Gaussian Splatting as Markov Chain Monte Carlo"): the reference
+# selects it with the "mcmc" preset (/root/reference/gs_init_compare/trainer.py:83-92:
+# init_opa 0.5, init_scale 0.1, opacity_reg / scale_reg 0.01) and drives it at
+# runner.py:214-215 (`initialize_state()`), 649-658 (`step_post_backward(..., lr=<means lr>)`).
+# gsplat's class is third-party and absent: restated from its published behaviour
+# (parity unpinned). The two per-Gaussian ops are HIP kernels (csrc/train_ops.hip).
+# ---------------------------------------------------------------------------------------
+def _call():
+    from ._lib import call
+    return call
+
+
+def _multinomial_sample(weights: Tensor, n: int, generator: Optional[torch.Generator] = None) -> Tensor:
+    """n draws with replacement, probability proportional to weights (torch.multinomial
+    is limited to 2^24 categories: fall back to inverse-CDF sampling above that)."""
+    if weights.numel() <= 2 ** 24:
+        return torch.multinomial(weights, n, replacement=True, generator=generator)
+    cdf = torch.cumsum(weights.double(), 0)
+    u = torch.rand(n, device=weights.device, dtype=torch.float64, generator=generator) * cdf[-1]
+    return torch.searchsorted(cdf, u).clamp_max(weights.numel() - 1)
+
+
+@torch.no_grad()
+def compute_relocation(opacities: Tensor, scales: Tensor, ratios: Tensor, binoms: Tensor):
+    """gsplat.relocation.compute_relocation on the HIP kernel: activated opacities [n],
+    scales [n,3], integer ratios [n] -> (new_opacities [n], new_scales [n,3])."""
+    n_max = binoms.shape[0]
+    opac = opacities.contiguous().float()
+    sc = scales.contiguous().float()
+    rat = ratios.clamp(1, n_max).to(torch.int32).contiguous()
+    bn = binoms.to(device=opac.device, dtype=torch.float32).contiguous()
+    new_o, new_s = torch.empty_like(opac), torch.empty_like(sc)
+    _call()("gsr_relocation", opac.numel(), opac.data_ptr(), sc.data_ptr(), rat.data_ptr(),
+            bn.data_ptr(), n_max, new_o.data_ptr(), new_s.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
+    return new_o, new_s
+
+
+@torch.no_grad()
+def inject_noise_to_position(params, optimizers, state, scaler: float,
+                             generator: Optional[torch.Generator] = None) -> None:
+    means = params["means"]
+    noise = torch.randn(means.shape, device=means.device, dtype=means.dtype, generator=generator)
+    _call()("gsr_inject_noise", means.shape[0], means.data_ptr(), params["quats"].data_ptr(),
+            params["scales"].data_ptr(), params["opacities"].data_ptr(), noise.data_ptr(),
+            float(scaler), torch.cuda.current_stream().cuda_stream)
+
+
+@torch.no_grad()
+def relocate(params, optimizers, state, mask: Tensor, binoms: Tensor, min_opacity: float = 0.005,
+             generator: Optional[torch.Generator] = None) -> None:
+    """Move the dead Gaussians (mask) onto alive ones sampled by opacity."""
+    opacities = torch.sigmoid(params["opacities"])
+    dead = mask.nonzero(as_tuple=True)[0]
+    alive = (~mask).nonzero(as_tuple=True)[0]
+    n = len(dead)
+    eps = torch.finfo(torch.float32).eps
+    sampled = alive[_multinomial_sample(opacities[alive].flatten(), n, generator)]
+    new_o, new_s = compute_relocation(
+        opacities[sampled], torch.exp(params["scales"])[sampled],
+        torch.bincount(sampled, minlength=len(opacities))[sampled] + 1, binoms)
+    new_o = torch.clamp(new_o, max=1.0 - eps, min=min_opacity)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        p = p.detach().clone()
+        if name == "opacities":
+            p[sampled] = torch.logit(new_o)
+        elif name == "scales":
+            p[sampled] = torch.log(new_s)
+        p[dead] = p[sampled]
+        return p
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        v[sampled] = 0
+        return v
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == len(opacities):
+            v[sampled] = 0
+
+
+@torch.no_grad()
+def sample_add(params, optimizers, state, n: int, binoms: Tensor, min_opacity: float = 0.005,
+               generator: Optional[torch.Generator] = None) -> None:
+    """Grow by n Gaussians cloned from ones sampled by opacity."""
+    opacities = torch.sigmoid(params["opacities"])
+    eps = torch.finfo(torch.float32).eps
+    sampled = _multinomial_sample(opacities.flatten(), n, generator)
+    new_o, new_s = compute_relocation(
+        opacities[sampled], torch.exp(params["scales"])[sampled],
+        torch.bincount(sampled, minlength=len(opacities))[sampled] + 1, binoms)
+    new_o = torch.clamp(new_o, max=1.0 - eps, min=min_opacity)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        p = p.detach().clone()
+        if name == "opacities":
+            p[sampled] = torch.logit(new_o)
+        elif name == "scales":
+            p[sampled] = torch.log(new_s)
+        return torch.cat([p, p[sampled]])
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        return torch.cat([v, torch.zeros((len(sampled), *v.shape[1:]), device=v.device, dtype=v.dtype)])
+
+    n_old = len(opacities)
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == n_old:
+            state[k] = torch.cat([v, torch.zeros((len(sampled), *v.shape[1:]), device=v.device, dtype=v.dtype)])
+
+
+@dataclass
+class MCMCStrategy:
+    cap_max: int = 1_000_000
+    noise_lr: float = 5e5
+    refine_start_iter: int = 500
+    refine_stop_iter: int = 25_000
+    refine_every: int = 100
+    min_opacity: float = 0.005
+    verbose: bool = False
+    seed: int = 42                      # shared by all replicas (sampling + noise must agree)
+
+    N_MAX = 51
+
+    def initialize_state(self) -> Dict[str, Any]:
+        binoms = torch.zeros((self.N_MAX, self.N_MAX))
+        for n in range(self.N_MAX):
+            for k in range(n + 1):
+                binoms[n, k] = math.comb(n, k)
+        return {"binoms": binoms, "generator": None}
+
+    def check_sanity(self, params, optimizers) -> None:
+        for key in ("means", "scales", "quats", "opacities"):
+            assert key in params, f"{key} is required in params"
+        assert set(params.keys()) <= set(optimizers.keys()), "every parameter needs an optimizer"
+
+    def step_pre_backward(self, params, optimizers, state, step: int, info) -> None:   # nothing to retain
+        return None
+
+    def _generator(self, state, device) -> torch.Generator:
+        if state.get("generator") is None:
+            g = torch.Generator(device=device)
+            g.manual_seed(self.seed)
+            state["generator"] = g
+        return state["generator"]
+
+    def step_post_backward(self, params, optimizers, state, step: int, info, lr: float, **_) -> None:
+        dev = params["means"].device
+        if state["binoms"].device != dev:
+            state["binoms"] = state["binoms"].to(dev)
+        binoms, gen = state["binoms"], self._generator(state, dev)
+        if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
+            n_rel = self._relocate_gs(params, optimizers, binoms, gen)
+            n_new = self._add_new_gs(params, optimizers, binoms, gen)
+            if self.verbose:
+                print(f"Step {step}: Relocated {n_rel} GSs. Added {n_new} GSs. "
+                      f"Now having {len(params['means'])} GSs.")
+        inject_noise_to_position(params, optimizers, {}, scaler=lr * self.noise_lr, generator=gen)
+
+    def _relocate_gs(self, params, optimizers, binoms, gen) -> int:
+        dead = torch.sigmoid(params["opacities"].flatten()) <= self.min_opacity
+        n = int(dead.sum().item())
+        if 0 < n < dead.numel():
+            relocate(params, optimizers, {}, dead, binoms, self.min_opacity, gen)
+        return n
+
+    def _add_new_gs(self, params, optimizers, binoms, gen) -> int:
+        cur = len(params["means"])
+        n = max(0, min(self.cap_max, int(1.05 * cur)) - cur)
+        if n > 0:
+            sample_add(params, optimizers, {}, n, binoms, self.min_opacity, gen)
+        return n

@@ -140,8 +140,15 @@ def main():
     # GSR_BENCH_FORCE_DIST=1 (under torchrun with one rank) rehearses the whole RCCL
     # path -- process group, gradient all-reduce, barrier, max-over-ranks -- on a 1-GPU box
     use_dist = world > 1 or (os.environ.get("GSR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    json_fd = None
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL prints a version banner on STDOUT when the communicator comes up; the
+        # contract is ONE JSON line on stdout, so send fd 1 to stderr for the run and keep
+        # a private handle on the real stdout for the result line
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
@@ -259,7 +266,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -231,6 +231,22 @@ int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_out, void *
  * camera-to-world). */
 int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation, void *stream);
 
+/* MCMC densification strategy (the reference drives gsplat's MCMCStrategy at
+ * gs_init_compare/runner.py:214-215, 649-658 with the "mcmc" preset of trainer.py:83-92).
+ * gsr_relocation replaces gsplat's `compute_relocation` CUDA op: for i < n,
+ *   N = clamp(ratios[i], 1, n_max); new_opacities[i] = 1 - (1 - opacities[i])^(1/N);
+ *   new_scales[i,:] = scales[i,:] * opacities[i] /
+ *       sum_{a=1..N} sum_{k=0..a-1} binoms[(a-1)*n_max + k] * (-1)^k / sqrt(k+1) * new_opacity^(k+1)
+ * (opacities / scales are ACTIVATED values, binoms is the [n_max,n_max] table C(n,k)).
+ * gsr_inject_noise replaces `inject_noise_to_position`: in place,
+ *   means[i] += Sigma_i * noise[i] * scaler / (1 + exp(-100 * ((1 - sigmoid(logit_opac[i])) - 0.995)))
+ * with Sigma_i from the un-normalised quats [N,4] (wxyz) and exp(log_scales [N,3]). */
+int gsr_relocation(int n, const float *opacities, const float *scales, const int32_t *ratios,
+                   const float *binoms, int n_max, float *new_opacities, float *new_scales,
+                   void *stream);
+int gsr_inject_noise(int N, float *means, const float *quats, const float *log_scales,
+                     const float *logit_opacities, const float *noise, float scaler, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.
  * coords arrays are int64 [2,M], row 0 = x, row 1 = y (the reference's

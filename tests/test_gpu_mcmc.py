@@ -1,0 +1,96 @@
+"""MCMC strategy: HIP relocation / noise kernels against
+oracle/strategy_oracle.py, the method's defining property, and an end-to-end run."""
+import importlib
+import math
+
+import pytest
+import torch
+
+from oracle import strategy_oracle as SO
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def S():
+    return importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+
+
+def test_relocation_kernel_vs_oracle_and_defining_property():
+    g = torch.Generator().manual_seed(0)
+    n = 500
+    op = torch.rand(n, generator=g) * 0.98 + 0.01
+    sc = torch.rand(n, 3, generator=g) * 0.1 + 0.001
+    ratios = torch.randint(1, 60, (n,), generator=g)          # > n_max exercises the clamp
+    st = S().MCMCStrategy().initialize_state()
+    new_o, new_s = S().compute_relocation(op.cuda(), sc.cuda(), ratios.cuda(), st["binoms"])
+    ref_o, ref_s = SO.compute_relocation(op, sc, ratios)
+    assert torch.allclose(new_o.cpu().double(), ref_o, rtol=2e-5, atol=1e-7)
+    # the alternating binomial sum cancels heavily for large N: fp32 keeps ~3 digits there
+    small = ratios <= 12
+    assert torch.allclose(new_s.cpu().double()[small], ref_s[small], rtol=2e-3)
+    assert torch.isfinite(new_s).all()
+    # N copies of the new opacity composite to the old one: 1 - (1 - o')^N = o
+    N = ratios.clamp(1, 51).double()
+    assert torch.allclose(1 - (1 - new_o.cpu().double()) ** N, op.double(), atol=2e-5)
+    # N = 1 is the identity
+    o1, s1 = S().compute_relocation(op.cuda(), sc.cuda(), torch.ones(n, dtype=torch.long).cuda(), st["binoms"])
+    assert torch.allclose(o1.cpu(), op, atol=1e-6) and torch.allclose(s1.cpu(), sc, rtol=1e-5)
+
+
+def test_inject_noise_kernel_vs_oracle():
+    lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    g = torch.Generator().manual_seed(1)
+    N = 4001
+    means = torch.randn(N, 3, generator=g)
+    quats = torch.randn(N, 4, generator=g)
+    ls = torch.randn(N, 3, generator=g) * 0.5 - 3.0
+    lo = torch.randn(N, generator=g) * 3.0 - 3.0               # mostly low opacity: the gate opens
+    noise = torch.randn(N, 3, generator=g)
+    scaler = 1.6e-4 * 5e5
+    ref = SO.inject_noise(means, quats, ls, lo, noise, scaler)
+    m, qd, lsd, lod, nd = means.cuda().clone(), quats.cuda(), ls.cuda(), lo.cuda(), noise.cuda()
+    lib.call("gsr_inject_noise", N, m.data_ptr(), qd.data_ptr(), lsd.data_ptr(), lod.data_ptr(),
+             nd.data_ptr(), scaler, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    moved = (ref - means.double()).abs().max()
+    assert moved > 1e-3                                         # the test is not vacuous
+    assert torch.allclose(m.cpu().double(), ref, rtol=1e-4, atol=1e-6 + 1e-4 * float(moved))
+
+
+def test_mcmc_training_relocates_dead_and_grows_to_cap():
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    N = 2000
+    sc = scenes.make_scene(N, 4, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 20, 40, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(4, H, W, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    logit_op = torch.logit(sc["opacities"])
+    logit_op[:300] = -8.0                                       # 300 dead Gaussians (opacity 3e-4)
+    splats, opts = runner.create_splats_with_optimizers(
+        sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)),
+        torch.log(sc["scales"]), quats=sc["quats"], opacities_logit=logit_op, shN=sc["shN"])
+    fused = D.fuse_optimizers(splats, opts)
+    strat = S().MCMCStrategy(cap_max=2300, refine_start_iter=2, refine_every=3, refine_stop_iter=100)
+    strat.check_sanity(splats, fused)
+    state = strat.initialize_state()
+    losses = []
+    for step in range(1, 14):
+        k = step % 4
+        loss, info = runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target[k:k + 1],
+                                       step=step, strategy=strat,
+                                       strategy_state=state, opacity_reg=0.01, scale_reg=0.01)
+        losses.append(float(loss))
+        n = len(splats["means"])
+        assert all(len(p) == n for p in splats.values())
+        for name, p in splats.items():
+            assert torch.isfinite(p).all(), name
+            st = fused[name].state.get(p, {})
+            if "exp_avg" in st:
+                assert st["exp_avg"].shape == p.shape
+    assert len(splats["means"]) == 2300                         # grew 5 % per refinement up to the cap
+    # nothing is left at the dead opacity: relocated onto alive Gaussians (>= min_opacity)
+    assert float(torch.sigmoid(splats["opacities"].detach()).min()) >= strat.min_opacity * 0.5
+    assert all(math.isfinite(x) for x in losses)
