@@ -1,0 +1,119 @@
+"""c3 (BASELINE.json configs[2]): monocular-depth initialisation at 1080p -- SfM reprojection,
+RANSAC (or LSQ) scale/shift alignment, stride-10 (or adaptive) subsampling, patch mask,
+unprojection -- for 15 images, about 300 k seed points. Prints one JSON line:
+images/s on the GPU (inputs resident in HBM), the CPU oracle chain's images/s beside it
+(the reference's own Python semantics, oracle/init_oracle.py), and the algorithmic bytes
+per image of SURVEY.md section 8d (5*H*W + 24*n).
+
+Usage (GPU box): python tools/bench_init.py [--images 15] [--aligner ransac|lstsqrs] [--subsample 10|adaptive]
+"""
+import argparse
+import importlib
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def scene(H, W, n_sfm, seed):
+    """d = 2 + 6*smoothstep + 0.05 N at 1080x1920; 4000 SfM samples, gt = 1.7 d + 0.4 + N(0, 0.02^2),
+    20 % gross outliers."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    t = torch.clamp((xx + 0.5 * yy) / 1.5, 0, 1)
+    pred = (2.0 + 6.0 * (t * t * (3 - 2 * t)) + 0.05 * torch.randn(H, W, generator=g)).float()
+    true_depth = 1.7 * pred + 0.4
+    mask = torch.rand(H, W, generator=g) > 0.03
+    K = torch.tensor([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1.0]])
+    th = 0.1 * seed
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.tensor([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    c2w[:3, 3] = torch.tensor([0.3, -0.2, 0.5])
+    xs = torch.rand(n_sfm, generator=g) * (W - 1)
+    ys = torch.rand(n_sfm, generator=g) * (H - 1)
+    z = true_depth[ys.round().long(), xs.round().long()] + 0.02 * torch.randn(n_sfm, generator=g)
+    outl = torch.rand(n_sfm, generator=g) < 0.2
+    z = torch.where(outl, z * (0.3 + 2.7 * torch.rand(n_sfm, generator=g)), z)
+    cam = torch.stack([(xs - K[0, 2]) / K[0, 0] * z, (ys - K[1, 2]) / K[1, 1] * z, z], 1)
+    world = (c2w[:3, :3] @ cam.T).T + c2w[:3, 3]
+    rgb = torch.rand(H, W, 3, generator=g)
+    return pred, mask, K, c2w, world.float(), rgb
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=15)
+    ap.add_argument("--aligner", default="ransac")
+    ap.add_argument("--subsample", default="10")
+    ap.add_argument("--cpu-images", type=int, default=2)
+    args = ap.parse_args()
+    H, W = 1080, 1920
+    pkg = "3dgs_monocular_depth_init_amd."
+    PF = importlib.import_module(pkg + "depth_prediction.points_from_depth")
+    cfgm = importlib.import_module(pkg + "config")
+    dac = importlib.import_module(pkg + "depth_alignment.config")
+    types = importlib.import_module(pkg + "types")
+    dpi = importlib.import_module(pkg + "depth_prediction.predictors.depth_predictor_interface")
+    from oracle import init_oracle as IO
+
+    sub = 10 if args.subsample == "10" else args.subsample
+    cfg = cfgm.Config()
+    cfg.mdi.subsample_factor = sub if sub == "adaptive" else int(sub)
+    cfg.mdi.alignment.aligner = dac.DepthAlignmentStrategyEnum(args.aligner)
+    scenes_ = [scene(H, W, 4000, s) for s in range(args.images)]
+    dev = [(dpi.PredictedDepth(depth=p.cuda(), mask=m.cuda()),
+            types.InputImage(data=rgb.cuda(), name=f"img{i}", cam2world=c2w, K=K), world.cuda())
+           for i, (p, m, K, c2w, world, rgb) in enumerate(scenes_)]
+
+    def gpu_pass():
+        n = 0
+        for pd, image, world in dev:
+            pts, fmask, P, rgbs = PF.get_pts_from_depth(pd, image, world, cfg, "cuda", return_rgb=True)
+            n += pts.shape[0]
+        torch.cuda.synchronize()
+        return n
+
+    torch.manual_seed(42)
+    gpu_pass()                                     # warm-up
+    torch.manual_seed(42)
+    t0 = time.perf_counter()
+    n_pts = gpu_pass()
+    dt_gpu = time.perf_counter() - t0
+
+    # CPU: the reference's Python semantics as restated by the oracle, same RNG stream
+    torch.manual_seed(42)
+    t0 = time.perf_counter()
+    for p, m, K, c2w, world, rgb in scenes_[:args.cpu_images]:
+        R, C = c2w[:3, :3].T, c2w[:3, 3]
+        P_o = (K @ R @ torch.hstack([torch.eye(3), -C[:, None]])).float()
+        co, de = IO.project_and_filter_sfm_pts(world, P_o, (W, H), m)
+        if args.aligner == "lstsqrs":
+            _, _, aligned = IO.lstsq_align(p, co, de)
+        else:
+            _, _, aligned, _, _ = IO.ransac_align(p, co, de, args.aligner, IO.RansacConfig())
+        out_depth, omask = IO.pipeline_align_noseg(aligned, m, m)
+        smask = (IO.static_mask((H, W), int(sub), omask) if sub != "adaptive"
+                 else IO.adaptive_mask((H, W, 3), out_depth.clone(), omask))
+        IO.assemble_mask_and_unproject(out_depth, omask, smask, K, c2w, co)
+    dt_cpu = (time.perf_counter() - t0) / max(args.cpu_images, 1)
+
+    per_img = 5 * H * W + 24 * (n_pts / args.images)
+    print(json.dumps({
+        "metric": "init images/s @1080p (c3: reprojection + %s alignment + subsample %s + unprojection)"
+                  % (args.aligner, args.subsample),
+        "value": args.images / dt_gpu, "unit": "images/s", "images": args.images, "seed_points": n_pts,
+        "ms_per_image": 1e3 * dt_gpu / args.images,
+        "algorithmic_bytes_per_image": per_img, "gbps": per_img * args.images / dt_gpu / 1e9,
+        "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "images/s", "kind": "port",
+                         "cores": torch.get_num_threads(), "sample": f"{args.cpu_images} images"},
+    }))
+
+
+if __name__ == "__main__":
+    main()
