@@ -1,14 +1,2 @@
-"""depth_subsampling/config.py:5-26 of the reference."""
-from dataclasses import dataclass
-
-
-@dataclass
-class AdaptiveSubsamplingConfig:
-    factor_range_min: int = 5
-    factor_range_max: int = 15
-
-
-@dataclass
-class NumSfMPointsMaskConfig:
-    num_patches_small_axis: int = 20
-    threshold: int = 15
+"""Import path of the reference kept; the definitions live in `contracts.py`."""
+from ..contracts import AdaptiveSubsamplingConfig, NumSfMPointsMaskConfig  # noqa: F401
