@@ -13,6 +13,22 @@
 
 namespace gsr {
 
+// Wave-cooperative read of the 64 consecutive shN rows [first_row, first_row + 64) (45 floats
+// each, one contiguous 11.5 KB block) into the wave's LDS slab as coalesced 16-byte loads:
+// 180 requests to L2 instead of the 768 that 64 lanes walking their own 180-byte rows make.
+// Afterwards lane l finds its row at slab + l*45 (bank-conflict free: 45 is odd). No
+// barrier: the slab belongs to one wave, whose LDS operations execute in program order.
+__device__ __forceinline__ void coop_load_rows45(const float *__restrict__ shN, int64_t first_row,
+                                                 float *__restrict__ slab, int lane) {
+  const float4 *src = reinterpret_cast<const float4 *>(shN + first_row * 45);
+  float4 *dst = reinterpret_cast<float4 *>(slab);
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int idx = it * 64 + lane;
+    if (idx < 64 * 45 / 4) dst[idx] = src[idx];
+  }
+}
+
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ opacities,
@@ -75,6 +91,8 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       float dz = mean[2] - campos[c * 3 + 2];
       float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
       const float *c0 = sh0 + (int64_t)i * sh0_stride;
+      // (a cooperative LDS read of the shN rows as in the backward was measured here and
+      // lost: 0.101 -> 0.112 ms, the 11.5 KB per wave caps this kernel at 3 waves/SIMD)
       const float *cn = shN + (int64_t)i * shN_stride;
       gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
                    [&](int k, float bk, float, float, float) {
@@ -134,6 +152,16 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 #pragma unroll
   for (int k = 0; k < 16; ++k) v_coef[k][0] = v_coef[k][1] = v_coef[k][2] = 0.f;
 
+  // shN rows of the wave, read cooperatively (see coop_load_rows45); the same slab later
+  // carries the v_shN rows out
+  const float *cn_row = shN ? shN + (int64_t)i * shN_stride : nullptr;
+  if (sh_degree > 0 && shN_stride == 45 && wave_full && ((((uintptr_t)shN) & 15) == 0)) {
+    const int lane = threadIdx.x & 63;
+    float *slab = &sT[(threadIdx.x >> 6) * (64 * 45)];
+    coop_load_rows45(shN, (int64_t)(i - lane), slab, lane);
+    cn_row = slab + lane * 45;
+  }
+
   for (int c = 0; c < C; ++c) {
     int64_t g = (int64_t)c * N + i;
     if (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) continue;
@@ -157,7 +185,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       float inv = 1.0f / nrm;
       float ux = dx * inv, uy = dy * inv, uz = dz * inv;
       const float *c0 = sh0 + (int64_t)i * sh0_stride;
-      const float *cn = shN + (int64_t)i * shN_stride;
+      const float *cn = cn_row;
       // pass 1: pre-clamp colour, for the clamp_min(., 0) mask
       float col[3] = {0.f, 0.f, 0.f};
       gs::sh_visit(sh_degree, ux, uy, uz, [&](int k, float b, float, float, float) {
