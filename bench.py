@@ -235,6 +235,17 @@ def main():
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         traffic = json.loads(pmc.read_text()).get(dom)
+    # The compositing kernels are bound by fp32 VALU issue, which the
+    # hbm|mfma roofline cannot express: report it beside the HBM figure. Instruction count per
+    # launch from the committed SQ_INSTS_VALU pass; a wave64 fp32 instruction occupies its
+    # SIMD's VALU for 4 cycles (1024 SIMDs, 2.4 GHz peak clock).
+    valu_issue = None
+    pv = ROOT / "profiles" / "pmc_valu.json"
+    if pv.exists() and dom_ms == dom_ms and dom_ms > 0:
+        n_inst = json.loads(pv.read_text()).get(dom)
+        if n_inst:
+            valu_issue = {"insts_per_launch": n_inst, "cycles_per_inst": 4, "simds": 1024,
+                          "clock_ghz": 2.4, "frac": n_inst * 4 / (1024 * dom_ms * 1e-3 * 2.4e9)}
 
     if rank == 0:
         line = {
@@ -256,6 +267,7 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                "valu_issue": valu_issue,
             },
             "iter_byte_model": {
                 "bytes_per_iter": iter_bytes,

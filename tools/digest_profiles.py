@@ -33,5 +33,13 @@ for k, cs in pmc.items():
     for frag, entry in names.items():
         if frag in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             traffic[entry] = int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
-json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
-print(json.dumps(traffic, indent=1))
+valu = {}
+for k, cs in pmc.items():
+    for frag, entry in names.items():
+        if frag in k and "SQ_INSTS_VALU" in cs:
+            valu[entry] = int(cs["SQ_INSTS_VALU"])
+if traffic:        # a digest of a counter set without FETCH/WRITE must not wipe the file
+    json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+if valu:
+    json.dump(valu, open("profiles/pmc_valu.json", "w"), indent=1, sort_keys=True)
+print(json.dumps({"traffic": traffic, "valu_insts": valu}, indent=1))
