@@ -1,0 +1,29 @@
+// adam_math.h -- the Adam update shared by gsr_adam_step (train_ops.hip) and the
+// optimizer-in-backward variant of the projection backward (project.hip).
+#pragma once
+#include "common.h"
+
+namespace gsr {
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1,
+                                         float beta2, float omb2, float eps, float step_size,
+                                         float bc2_sqrt) {
+  // same operation order as torch.optim.Adam (_single_tensor_adam)
+  m = m + (g - m) * omb1;                            // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * beta2 + omb2 * g * g;                      // mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);                   // addcdiv_(exp_avg, denom, -step_size)
+}
+
+// Parameter tensors of the optimizer-in-backward path, in this order.
+enum { AF_MEANS = 0, AF_QUATS, AF_SCALES, AF_OPAC, AF_SH0, AF_SHN, AF_COUNT };
+struct AdamFused {
+  float *p[AF_COUNT];          // parameters (updated in place)
+  float *m[AF_COUNT];          // exp_avg
+  float *v[AF_COUNT];          // exp_avg_sq
+  float step_size[AF_COUNT];   // lr / (1 - beta1^t)
+  float bc2_sqrt[AF_COUNT];    // sqrt(1 - beta2^t)
+  float beta2, eps, omb1, omb2;
+};
+
+}  // namespace gsr

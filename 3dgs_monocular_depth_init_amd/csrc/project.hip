@@ -9,6 +9,7 @@
 // Gaussian backward (cameras summed in registers, so no atomics and every
 // output is written exactly once).
 #include "common.h"
+#include "adam_math.h"
 #include "gs_math.h"
 
 namespace gsr {
@@ -119,6 +120,10 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 }
 
 // One thread per Gaussian; loops over cameras.
+// FUSE_ADAM: optimizer in backward -- instead of writing the six gradients (and reading them
+// and the parameters back in gsr_adam_step), each thread applies the Adam update of its
+// Gaussian right here; the shN block is updated in the transposed (coalesced) domain.
+template <bool FUSE_ADAM>
 __global__ void __launch_bounds__(256, 2)
 project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ viewmats,
@@ -130,11 +135,13 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    int depth_channel, float *__restrict__ v_means, float *__restrict__ v_quats,
                    float *__restrict__ v_scales, float *__restrict__ v_sh0, int v_sh0_stride,
                    float *__restrict__ v_shN, int v_shN_stride, int sh_K, int activations,
-                   const float *__restrict__ opacities_act, float *__restrict__ v_opacities) {
+                   const float *__restrict__ opacities_act, float *__restrict__ v_opacities,
+                   AdamFused af) {
   __shared__ __attribute__((aligned(16))) float sT[4 * 64 * 45];   // per-wave transpose slabs
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   // all 64 rows of this wave exist and v_shN is 16-byte aligned at the wave's first row
-  const bool wave_full = ((i | 63) < N) && v_shN && ((((uintptr_t)v_shN) & 15) == 0);
+  const bool wave_full = ((i | 63) < N) &&
+                         (FUSE_ADAM ? (sh_degree >= 0) : (v_shN && ((((uintptr_t)v_shN) & 15) == 0)));
   if (i >= N) return;
   float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
   float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
@@ -217,6 +224,73 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   }
   float v_q[4], v_s[3];
   gs::quat_scale_to_covar_vjp(q, s, v_covar, v_q, v_s);
+  if (activations & GSR_ACT_EXP_SCALES) {   // d exp(x) = exp(x)
+    v_s[0] *= s[0];
+    v_s[1] *= s[1];
+    v_s[2] *= s[2];
+  }
+  if (activations & GSR_ACT_SIGMOID_OPAC) {  // sum over cameras of the compositing gradient
+    const float o = opacities_act ? opacities_act[i] : 0.f;
+    v_op *= o * (1.0f - o);
+  }
+  if constexpr (FUSE_ADAM) {
+    auto step = [&](int t, int64_t off, float g) {
+      float pp = af.p[t][off], mm = af.m[t][off], vv = af.v[t][off];
+      adam_one(pp, g, mm, vv, af.omb1, af.beta2, af.omb2, af.eps, af.step_size[t], af.bc2_sqrt[t]);
+      af.p[t][off] = pp;
+      af.m[t][off] = mm;
+      af.v[t][off] = vv;
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) step(AF_MEANS, (int64_t)i * 3 + k, v_mean[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) step(AF_QUATS, (int64_t)i * 4 + k, v_q[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) step(AF_SCALES, (int64_t)i * 3 + k, v_s[k]);
+    step(AF_OPAC, i, v_op);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) step(AF_SH0, (int64_t)i * 3 + k, v_coef[0][k]);
+    if (wave_full && ((((uintptr_t)af.p[AF_SHN]) | ((uintptr_t)af.m[AF_SHN]) |
+                       ((uintptr_t)af.v[AF_SHN])) & 15) == 0) {
+      // gradients into the slab (transposed), then Adam on coalesced 16-byte pieces of
+      // the wave's contiguous 64 x 45 block of p / exp_avg / exp_avg_sq
+      float *slab = &sT[(threadIdx.x >> 6) * (64 * 45)];
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        slab[lane * 45 + (k - 1) * 3 + 0] = v_coef[k][0];
+        slab[lane * 45 + (k - 1) * 3 + 1] = v_coef[k][1];
+        slab[lane * 45 + (k - 1) * 3 + 2] = v_coef[k][2];
+      }
+      const int64_t base = (int64_t)(i - lane) * 45;
+      float4 *P4 = reinterpret_cast<float4 *>(af.p[AF_SHN] + base);
+      float4 *M4 = reinterpret_cast<float4 *>(af.m[AF_SHN] + base);
+      float4 *V4 = reinterpret_cast<float4 *>(af.v[AF_SHN] + base);
+      const float4 *G4 = reinterpret_cast<const float4 *>(slab);
+      const float ss = af.step_size[AF_SHN], bc2 = af.bc2_sqrt[AF_SHN];
+#pragma unroll 4
+      for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < 64 * 45 / 4) {
+          float4 pp = P4[idx], mm = M4[idx], vv = V4[idx];
+          const float4 gg = G4[idx];
+          adam_one(pp.x, gg.x, mm.x, vv.x, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+          adam_one(pp.y, gg.y, mm.y, vv.y, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+          adam_one(pp.z, gg.z, mm.z, vv.z, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+          adam_one(pp.w, gg.w, mm.w, vv.w, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+          P4[idx] = pp;
+          M4[idx] = mm;
+          V4[idx] = vv;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 1; k < 16; ++k)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) step(AF_SHN, (int64_t)i * 45 + (k - 1) * 3 + ch, v_coef[k][ch]);
+    }
+    return;
+  }
   v_means[i * 3 + 0] = v_mean[0];
   v_means[i * 3 + 1] = v_mean[1];
   v_means[i * 3 + 2] = v_mean[2];
@@ -224,21 +298,10 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   v_quats[i * 4 + 1] = v_q[1];
   v_quats[i * 4 + 2] = v_q[2];
   v_quats[i * 4 + 3] = v_q[3];
-  if (activations & GSR_ACT_EXP_SCALES) {   // d exp(x) = exp(x)
-    v_s[0] *= s[0];
-    v_s[1] *= s[1];
-    v_s[2] *= s[2];
-  }
   v_scales[i * 3 + 0] = v_s[0];
   v_scales[i * 3 + 1] = v_s[1];
   v_scales[i * 3 + 2] = v_s[2];
-  if (v_opacities) {                         // sum over cameras of the compositing gradient
-    if (activations & GSR_ACT_SIGMOID_OPAC) {
-      const float o = opacities_act[i];
-      v_op *= o * (1.0f - o);
-    }
-    v_opacities[i] = v_op;
-  }
+  if (v_opacities) v_opacities[i] = v_op;
   if (v_sh0) {
     float *o0 = v_sh0 + (int64_t)i * v_sh0_stride;
     o0[0] = v_coef[0][0];
@@ -352,12 +415,57 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
   GSR_REQUIRE(!(activations & GSR_ACT_SIGMOID_OPAC) || !v_opacities || opacities_act,
               "project_bwd: sigmoid chain rule needs the activated opacities");
   dim3 grid((unsigned)gsr::ceil_div(N, 256));
-  hipLaunchKernelGGL(gsr::project_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
-                     quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree, sh0,
-                     sh0_stride, shN, shN_stride, radii, grad_rows, v_depths, v_compensations,
+  hipLaunchKernelGGL(gsr::project_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
+                     means, quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree,
+                     sh0, sh0_stride, shN, shN_stride, radii, grad_rows, v_depths, v_compensations,
                      depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
                      v_sh0_stride, v_shN, v_shN_stride, sh_K, activations, opacities_act,
-                     v_opacities);
+                     v_opacities, gsr::AdamFused{});
   GSR_CHECK_LAUNCH("project_bwd");
+  return GSR_OK;
+}
+
+// Optimizer in backward: gsr_project_bwd and gsr_adam_step in one pass. The six parameter
+// tensors (means, quats, raw scales, raw opacities, sh0 [N,1,3], shN [N,15,3]) are updated
+// in place from the gradients this backward produces; no gradient tensor is written.
+extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks,
+                                    const float *campos, int width, int height, float eps2d,
+                                    int sh_degree, const int32_t *radii, const float *grad_rows,
+                                    const float *v_depths, const float *v_compensations,
+                                    int depth_channel, int activations, const float *opacities_act,
+                                    void *const *params, void *const *exp_avg,
+                                    void *const *exp_avg_sq, const float *step_size,
+                                    const float *bc2_sqrt, double beta1_d, double beta2_d,
+                                    double eps_d, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd_adam: bad sizes");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(viewmats && Ks && campos && radii && grad_rows && params && exp_avg && exp_avg_sq &&
+                  step_size && bc2_sqrt,
+              "project_bwd_adam: null pointer");
+  GSR_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_bwd_adam: sh_degree %d", sh_degree);
+  GSR_REQUIRE(activations == (GSR_ACT_EXP_SCALES | GSR_ACT_SIGMOID_OPAC) && opacities_act,
+              "project_bwd_adam: raw scales / raw opacities (fused activations) required");
+  GSR_REQUIRE(depth_channel < 5, "project_bwd_adam: depth_channel out of range");
+  gsr::AdamFused af;
+  for (int t = 0; t < gsr::AF_COUNT; ++t) {
+    GSR_REQUIRE(params[t] && exp_avg[t] && exp_avg_sq[t], "project_bwd_adam: tensor %d is null", t);
+    af.p[t] = (float *)params[t];
+    af.m[t] = (float *)exp_avg[t];
+    af.v[t] = (float *)exp_avg_sq[t];
+    af.step_size[t] = step_size[t];
+    af.bc2_sqrt[t] = bc2_sqrt[t];
+  }
+  af.beta2 = (float)beta2_d;
+  af.eps = (float)eps_d;
+  af.omb1 = (float)(1.0 - beta1_d);
+  af.omb2 = (float)(1.0 - beta2_d);
+  dim3 grid((unsigned)gsr::ceil_div(N, 256));
+  hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
+                     af.p[gsr::AF_MEANS], af.p[gsr::AF_QUATS], af.p[gsr::AF_SCALES], viewmats, Ks,
+                     campos, width, height, eps2d, sh_degree, af.p[gsr::AF_SH0], 3,
+                     af.p[gsr::AF_SHN], 45, radii, grad_rows, v_depths, v_compensations,
+                     depth_channel, nullptr, nullptr, nullptr, nullptr, 3, nullptr, 45, 16,
+                     activations, opacities_act, nullptr, af);
+  GSR_CHECK_LAUNCH("project_bwd_adam");
   return GSR_OK;
 }

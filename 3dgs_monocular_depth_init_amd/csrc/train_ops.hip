@@ -3,6 +3,7 @@
 // the six per-parameter torch.optim.Adam steps of
 // gs_init_compare/runner.py:129-137, 676-679 (7 x 236 MB of HBM traffic at
 // 1M Gaussians: read p,g,m,v, write p,m,v -- streamed once, 16 B per lane).
+#include "adam_math.h"
 #include "common.h"
 #include "gs_math.h"
 
@@ -24,16 +25,6 @@ struct AdamArgs {
   float omb1, omb2;                        // 1-beta1, 1-beta2 rounded from fp64 (as torch does)
   int n;
 };
-
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1,
-                                         float beta2, float omb2, float eps, float step_size,
-                                         float bc2_sqrt) {
-  // same operation order as torch.optim.Adam (_single_tensor_adam)
-  m = m + (g - m) * omb1;                            // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * beta2 + omb2 * g * g;                      // mul_(beta2).addcmul_(g, g, 1 - beta2)
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - step_size * (m / denom);                   // addcdiv_(exp_avg, denom, -step_size)
-}
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   int t = 0;

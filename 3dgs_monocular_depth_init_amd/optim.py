@@ -133,6 +133,58 @@ class FusedAdam:
         self._launch([(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), ss, bc2)
                       for _, p, g, m, v, ss, bc2 in items], beta1, beta2, eps)
 
+    # ---- optimizer in backward ------------------------------------------------------
+    FUSED_ORDER = ("means", "quats", "scales", "opacities", "sh0", "shN")
+
+    def fuse_into_backward(self, enable: bool = True) -> None:
+        """Single-process training with a purely photometric loss: let the projection
+        backward apply this optimizer's update itself (`gsr_project_bwd_adam`) -- the
+        parameter gradients are then never written to memory nor read back, and
+        `step()` finds nothing left to do. Do NOT enable together with a gradient
+        all-reduce, gradient clipping, or loss terms that reach the parameters outside
+        the rasterizer (their gradients would be applied without this step's moments),
+        nor with more than one backward per step."""
+        from .rendering import set_backward_optimizer
+        set_backward_optimizer(self if enable else None)
+
+    @torch.no_grad()
+    def claim(self, tensors):
+        """Called by the projection backward with its six parameter inputs. Returns the
+        launch arguments (and advances `step`) when they are exactly this optimizer's
+        parameters, else None."""
+        if any(n not in self.optimizers for n in self.FUSED_ORDER):
+            return None
+        ps, ms, vs, ss, bc2 = [], [], [], [], []
+        beta1 = beta2 = eps = None
+        states = []
+        for name, t in zip(self.FUSED_ORDER, tensors):
+            opt = self.optimizers[name]
+            grp = opt.param_groups[0]
+            p = grp["params"][0]
+            if t is None or p.data_ptr() != t.data_ptr() or p.shape != t.shape or not p.is_contiguous() \
+                    or p.dtype != torch.float32 or not p.is_cuda:
+                return None
+            b1, b2 = grp["betas"]
+            if beta1 is None:
+                beta1, beta2, eps = float(b1), float(b2), float(grp["eps"])
+            elif (float(b1), float(b2), float(grp["eps"])) != (beta1, beta2, eps):
+                return None
+            states.append((opt, grp, p))
+        for opt, grp, p in states:
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            t = float(st["step"])
+            ps.append(p.data_ptr()); ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
+            ss.append(float(grp["lr"]) / (1.0 - beta1 ** t))
+            bc2.append((1.0 - beta2 ** t) ** 0.5)
+        PA = C.c_void_p * 6
+        FA = C.c_float * 6
+        return PA(*ps), PA(*ms), PA(*vs), FA(*ss), FA(*bc2), beta1, beta2, eps
+
     def zero_grad(self, set_to_none: bool = True) -> None:
         for opt in self.optimizers.values():
             opt.zero_grad(set_to_none=set_to_none)

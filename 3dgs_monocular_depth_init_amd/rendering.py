@@ -87,6 +87,17 @@ class GradArena:
 
 _GRAD_ARENA: Optional[GradArena] = None
 
+# Optimizer in backward (optim.FusedAdam.fuse_into_backward): when set, the projection
+# backward applies the Adam update itself (gsr_project_bwd_adam) and returns no parameter
+# gradients. `claim(tensors)` returns the launch arguments for exactly these six parameter
+# tensors, or None when the fused step does not apply to this call.
+_BACKWARD_OPTIMIZER = None
+
+
+def set_backward_optimizer(obj) -> None:
+    global _BACKWARD_OPTIMIZER
+    _BACKWARD_OPTIMIZER = obj
+
 
 def set_grad_arena(arena: Optional[GradArena]) -> None:
     global _GRAD_ARENA
@@ -166,6 +177,7 @@ class _ProjectSH(torch.autograd.Function):
              ptr(records), _stream())
         ctx.cfg = cfg
         ctx.split = sh_b is not None
+        ctx.raw_opacities = opacities      # identity only (optimizer in backward); not read
         ctx.save_for_backward(means, quats, scales, sh_a, sh_b, viewmats, Ks, campos, radii,
                               opac_act)
         if comps is None:
@@ -198,6 +210,25 @@ class _ProjectSH(torch.autograd.Function):
             # the kernel sums rows[.][GR_OPAC] over cameras and applies o(1-o)
             if not fast and v_opac_act is not None:
                 rows.view(C, N, GRAD_ROW)[0, :, GR_OPAC] = v_opac_act.reshape(N)
+        if v_depths is not None:
+            v_depths = _f32c(v_depths)
+        if v_comps is not None and calc_comp:
+            v_comps = _f32c(v_comps)
+        else:
+            v_comps = None
+        bo = _BACKWARD_OPTIMIZER
+        if (bo is not None and ctx.split and sh_degree >= 0 and sh_b is not None
+                and sh_b.shape[1] == 15 and activations == (ACT_EXP_SCALES | ACT_SIGMOID_OPAC)
+                and all(ctx.needs_input_grad[:6])):
+            args = bo.claim((means, quats, scales, ctx.raw_opacities, sh_a, sh_b))
+            if args is not None:
+                P, M, V, ss, bc2, beta1, beta2, eps = args
+                call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
+                     height, eps2d, sh_degree, ptr(radii), ptr(rows), ptr(v_depths), ptr(v_comps),
+                     depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2, beta1, beta2,
+                     eps, _stream())
+                return (None,) * 10
+        if activations & ACT_SIGMOID_OPAC:
             v_opacities = _grad_out("opacities", opac_act)
         v_means = _grad_out("means", means)
         v_quats = _grad_out("quats", quats)
@@ -221,12 +252,6 @@ class _ProjectSH(torch.autograd.Function):
                 v_sh0_ptr, v_shN_ptr = v_sh_a.data_ptr(), v_sh_b.data_ptr()
                 sh0_stride, shN_stride = 3, 3 * (K - 1)
                 v0_stride, vN_stride = 3, 3 * (K - 1)
-        if v_depths is not None:
-            v_depths = _f32c(v_depths)
-        if v_comps is not None and calc_comp:
-            v_comps = _f32c(v_comps)
-        else:
-            v_comps = None
         call("gsr_project_bwd", C, N, ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
              ptr(campos), width, height, eps2d, sh_degree, sh0_ptr, sh0_stride, shN_ptr,
              shN_stride, ptr(radii), None, None, ptr(rows), ptr(v_depths), ptr(v_comps),

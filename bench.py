@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=N_GAUSS)
+    ap.add_argument("--separate-adam", action="store_true",
+                    help="N=1: keep gsr_project_bwd and gsr_adam_step as two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true",
                     help="time fwd+bwd only (the reported line always includes Adam)")
@@ -172,6 +174,10 @@ def main():
     gen = torch.Generator().manual_seed(2)
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
     cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
+    if not use_dist and not args.no_optimizer and not args.separate_adam:
+        # one process, photometric loss only: the projection backward applies the Adam update
+        # itself (gsr_project_bwd_adam); with an all-reduce in between the two stay separate
+        optimizers.fuse_into_backward(True)
     sync = distributed.GradSync(splats, world, force=use_dist) if use_dist else None
     if sync is not None and not args.no_optimizer:
         sync.attach(optimizers)      # Adam on chunk k overlaps the all-reduce of chunk k+1

@@ -104,6 +104,22 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
                                           (times o(1-o) with GSR_ACT_SIGMOID_OPAC) */,
                     void *stream);
 
+/* Optimizer in backward (A8 fused into the backward of A1+A3+A4): gsr_project_bwd and
+ * gsr_adam_step in ONE pass over the parameters, for the single-process case where nothing
+ * (no all-reduce, no other loss term) has to see the parameter gradients. params /
+ * exp_avg / exp_avg_sq: HOST arrays of 6 device pointers in the order
+ * means [N,3], quats [N,4], raw scales [N,3], raw opacities [N], sh0 [N,1,3], shN [N,15,3];
+ * step_size[6] = lr/(1-beta1^t), bc2_sqrt[6] = sqrt(1-beta2^t) (HOST). The parameters are
+ * read as the inputs of the backward and updated in place; no gradient is written.
+ * Requires activations == GSR_ACT_EXP_SCALES | GSR_ACT_SIGMOID_OPAC. */
+int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks, const float *campos,
+                         int width, int height, float eps2d, int sh_degree, const int32_t *radii,
+                         const float *grad_rows, const float *v_depths,
+                         const float *v_compensations, int depth_channel, int activations,
+                         const float *opacities_act, void *const *params, void *const *exp_avg,
+                         void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
+                         double beta1, double beta2, double eps, void *stream);
+
 /* ---------------------------------------------------------------------------
  * A5: per-tile depth-sorted intersection lists.
  * tile ids are c*tile_h*tile_w + ty*tile_w + tx; n_tiles = C*tile_h*tile_w.

@@ -216,3 +216,48 @@ def test_pipelined_allreduce_adam_equals_plain_step_rccl_world1():
     finally:
         dist.destroy_process_group()
         R.set_grad_arena(None)
+
+
+def test_optimizer_in_backward_equals_separate_step():
+    """FusedAdam.fuse_into_backward(): the projection backward applies the Adam update itself
+    (gsr_project_bwd_adam). Three steps (SH degree 3, then degree 1 so that the unused bands
+    see zero gradients) must match backward + gsr_adam_step; p.grad stays None."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 3001                                      # not a multiple of 64: the last wave is partial
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 30, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(fused_bwd):
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)),
+            torch.log(sc["scales"]), quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]),
+            shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        try:
+            if fused_bwd:
+                fused.fuse_into_backward(True)
+            for k, step in enumerate((5000, 5001, 1200)):
+                runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target, step=step)
+                assert all(p.grad is None for p in splats.values())
+        finally:
+            R.set_backward_optimizer(None)
+        torch.cuda.synchronize()
+        state = {n: {a: b.clone() for a, b in fused[n].state[splats[n]].items()} for n in splats}
+        return {n: p.detach().clone() for n, p in splats.items()}, state
+
+    p_sep, s_sep = run(False)
+    p_fus, s_fus = run(True)
+    for n in p_sep:
+        assert float(s_fus[n]["step"]) == 3.0, n
+        assert torch.allclose(p_sep[n], p_fus[n], rtol=1e-5, atol=1e-6), n
+        for a in ("exp_avg", "exp_avg_sq"):
+            x, y = s_sep[n][a], s_fus[n][a]
+            assert torch.allclose(x, y, rtol=1e-3, atol=1e-5 * float(x.abs().max())), (n, a)
+    # and the parameters did move
+    assert float((p_fus["shN"] - sc["shN"].cuda()).abs().max()) > 0
