@@ -55,7 +55,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
     px[q] = (float)x + 0.5f;
     T[q] = 1.0f;
-    last[q] = -1;
+    last[q] = 0x7fffffff;   // "never terminated": resolved to the end of the list at the end
     if (x >= width || y >= height) {
       outside |= 1u << q;
       px[q] = PIX_DONE;
@@ -112,8 +112,6 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
       if (CH > 2) col[2] = sRec[buf][2][j].x;
       if (CH > 3) col[3] = sRec[buf][2][j].y;
       if (CH > 4) col[4] = sRec[buf][2][j].z;
-      int idx_v;   // list position in a VGPR (v_cndmask cannot take it from an SGPR next to vcc)
-      asm("v_mov_b32 %0, %1" : "=v"(idx_v) : "s"(base + j));
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (qm & (3u << (2 * r))) {   // scalar: this row of quadrants is touched
@@ -127,7 +125,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
               const float sg = sigma_l2(Ac.z, dx, Br, Cr);
               const float ov = Bc.y * __builtin_amdgcn_exp2f(-sg);
               // valid <=> sigma >= 0 and alpha >= 1/255 (<=> ov >= 1/255): one compare
-              bool ok = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
+              const bool ok = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
               float a = ok ? (NOCLAMP ? ov : fminf(gs::ALPHA_MAX, ov)) : 0.f;
               float nT = fmaf(-a, T[q], T[q]);
               if (__any(nT <= gs::T_THRESHOLD)) {   // rare: a pixel finishes at this Gaussian
@@ -135,13 +133,12 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                 a = stop ? 0.f : a;
                 nT = stop ? T[q] : nT;
                 px[q] = stop ? PIX_DONE : px[q];
-                ok = ok && !stop;
+                last[q] = stop ? base + j - 1 : last[q];   // this one is NOT blended
               }
               const float w = a * T[q];
               T[q] = nT;
 #pragma unroll
               for (int k = 0; k < CH; ++k) acc[q][k] = fmaf(col[k], w, acc[q][k]);
-              last[q] = ok ? idx_v : last[q];
             }
           }
         }
@@ -167,7 +164,10 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
       out[k] = v;
     }
     render_alphas[pix] = 1.0f - T[q];
-    last_ids[pix] = last[q];
+    // list position after which nothing is blended into this pixel: where it terminated, else
+    // the end of the tile's list (the backward re-tests alpha >= 1/255 per pair itself, so the
+    // exact position of the last contributor is not needed and not tracked)
+    last_ids[pix] = (last[q] == 0x7fffffff) ? e - 1 : last[q];
   }
 }
 

@@ -150,8 +150,9 @@ int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
 /* ---------------------------------------------------------------------------
  * A6 / A7: alpha compositing, one wave64 per 16x16 tile (four 8x8 quadrants,
  * one pixel of each per lane). backgrounds [C,CH] or NULL. last_ids [C,H,W] int32 is
- * the flat index (into flatten_ids) of the last Gaussian blended into a pixel, -1 if
- * none. tile_order (from gsr_isect_scan) is the order workgroups take tiles in;
+ * the position (in flatten_ids) after which nothing is blended into a pixel: the entry
+ * before the one at which the pixel's transmittance fell to 1e-4, else the last entry of
+ * the tile's list (first entry - 1 for an empty list). tile_order (from gsr_isect_scan) is the order workgroups take tiles in;
  * NULL = natural order.
  * --------------------------------------------------------------------------*/
 /* A5, bucketed variant (isect_bucket.hip): same outputs as count/scan/emit/sort
