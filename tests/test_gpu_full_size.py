@@ -145,3 +145,36 @@ def test_c4_directional_finite_difference(R):
         fd = (loss(plus) - loss(minus)) / (2 * eps)
         an = float((grads[name].double() * d.double()).sum())
         assert fd == pytest.approx(an, rel=5e-2, abs=1e-7), f"{name}: fd {fd:.4e} vs analytic {an:.4e}"
+
+
+def _c2_vs_oracle(width, height, cx, cy):
+    import time
+    from tests.test_gpu_rasterization import _check, _run_both
+    Rm = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    sc = scenes.make_scene(100_000, 0)
+    vm, K = scenes.cameras([25])
+    K = K.clone()
+    K[0, 0, 2], K[0, 1, 2] = cx, cy
+    t0 = time.perf_counter()
+    out = _run_both(Rm, sc, vm, K, width, height, split=True)
+    print(f"c2 view {width}x{height}: oracle + HIP fwd+bwd {time.perf_counter() - t0:.1f} s")
+    # ~40 fp32 terms per pixel: the mean error sits at 1e-6, the per-pixel bound stays 1e-4.
+    # Threshold flips (a pair within rounding of alpha = 1/255 blended by one side only; sigma
+    # is evaluated in a different but equivalent order here) touch ~12 of the 100 k Gaussians
+    # at the full frame, i.e. 1.2e-4 of the gradient elements: allowed fraction 2e-4.
+    _check(*out, mean_frac=5e-2, flip_frac=2e-4)
+
+
+def test_c2_window_vs_oracle():
+    """BASELINE config c2 (100 k Gaussians, camera 25 of the 1080p rig) against the CPU oracle,
+    forward and backward, on a 512x512 window of the frame (principal point shifted, same
+    focal length): footprints and list lengths are those of the full frame, the oracle's
+    tile loop is 8x shorter."""
+    _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("GSR_SLOW_TESTS") != "1",
+                    reason="full 1080p frame: the CPU oracle needs ~100 s (set GSR_SLOW_TESTS=1)")
+def test_c2_one_view_full_size_vs_oracle():
+    """The same at the real 1920x1080 (passes; kept out of the default run for its duration)."""
+    _c2_vs_oracle(W, H, 960.0, 540.0)

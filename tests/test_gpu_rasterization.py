@@ -60,7 +60,8 @@ def _run_both(R, sc, vm, K, W, H, *, sh_degree=3, render_mode="RGB", backgrounds
     return cpu, gpu, (rc_c, ra_c, meta_c), (rc_g, ra_g, meta_g)
 
 
-def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL):
+def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL, mean_frac=1e-2,
+           flip_frac=1e-4):
     rc_c, ra_c, meta_c = out_c
     rc_g, ra_g, meta_g = out_g
     vis_c = (meta_c["radii"] > 0).all(-1)
@@ -79,10 +80,10 @@ def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL):
         # ~alpha*colour = 4e-3. Such flips are allowed on <= 1e-4 of the pixels;
         # everything else must be within img_atol, and the mean error far below it.
         n_bad = int((err > img_atol).sum())
-        assert n_bad <= max(1, math.ceil(1e-4 * err.numel())), f"{name}: {n_bad} px > {img_atol}"
+        assert n_bad <= max(1, math.ceil(flip_frac * err.numel())), f"{name}: {n_bad} px > {img_atol}"
         flip = FLIP_ATOL * max(1.0, float(ref.detach().abs().max()))
         assert err.max().item() <= flip, f"{name} max abs err {err.max().item():.3e}"
-        assert err.mean().item() <= img_atol * 1e-2, f"{name} mean abs err {err.mean().item():.3e}"
+        assert err.mean().item() <= img_atol * mean_frac, f"{name} mean abs err {err.mean().item():.3e}"
     for k in cpu:
         if cpu[k].grad is None:
             assert gpu[k].grad is None or gpu[k].grad.abs().max().item() == 0.0
@@ -96,7 +97,7 @@ def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL):
         assert l2 <= grad_rtol, f"grad {k}: L2 rel err {l2:.3e}"
         tol = grad_rtol * float(ref.abs().max())
         n_bad = int(((got - ref).abs() > tol).sum())
-        assert n_bad <= max(1, math.ceil(1e-4 * ref.numel())), f"grad {k}: {n_bad} elements off by > {tol:.2e}"
+        assert n_bad <= max(1, math.ceil(flip_frac * ref.numel())), f"grad {k}: {n_bad} elements off by > {tol:.2e}"
         assert _rel(got, ref) <= 50 * grad_rtol, f"grad {k}: max rel err {_rel(got, ref):.3e}"
 
 
