@@ -26,7 +26,9 @@ from ..config import RansacConfig
 from ..interface import DepthAlignmentResult, DepthAlignmentStrategy
 from .lstsqrs import apply_scale_shift, gather_depth
 
-CHUNK = 256
+CHUNK = 256          # largest chunk of iterations evaluated per round trip
+FIRST_CHUNK = 16     # chunks grow 16, 32, ... CHUNK: the adaptive stop usually fires within the
+                     # first dozens of iterations and every drawn randperm costs host time
 
 
 def _st():
@@ -92,8 +94,10 @@ def _align_depth_ransac_generic(predicted_depth, gt_points_camera_coords, gt_dep
     done = False
     base = 0
     required = 0          # _required_samples(0, ...) == 0: ZeroDivisionError branch
+    chunk = FIRST_CHUNK
     while base < p.max_iters and not done:
-        T = min(CHUNK, p.max_iters - base)
+        T = min(chunk, p.max_iters - base)
+        chunk = min(2 * chunk, CHUNK)
         rng_state = torch.get_rng_state()
         sample_idx = torch.stack([torch.randperm(num_samples)[: p.sample_size] for _ in range(T)])
         h_s, l_r, l_m, h_lo, lo_r, lo_m, lo_in = _evaluate_chunk(d, g, sample_idx, p.inlier_threshold)
