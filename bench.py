@@ -243,15 +243,19 @@ def main():
         traffic = json.loads(pmc.read_text()).get(dom)
     # The compositing kernels are bound by fp32 VALU issue, which the
     # hbm|mfma roofline cannot express: report it beside the HBM figure. Instruction count per
-    # launch from the committed SQ_INSTS_VALU pass; a wave64 fp32 instruction occupies its
-    # SIMD's VALU for 4 cycles (1024 SIMDs, 2.4 GHz peak clock).
+    # launch from the committed SQ_INSTS_VALU pass; cycles per wave64 instruction per SIMD =
+    # kernel time x 1024 SIMDs x 2.4 GHz / instructions. Reference rates measured with
+    # tools/dbg/ubench/valu_rate.hip on the same hardware: a dependent chain issues at 4.3
+    # cycles per instruction whatever the occupancy, independent instructions at 2.7.
     valu_issue = None
     pv = ROOT / "profiles" / "pmc_valu.json"
     if pv.exists() and dom_ms == dom_ms and dom_ms > 0:
         n_inst = json.loads(pv.read_text()).get(dom)
         if n_inst:
-            valu_issue = {"insts_per_launch": n_inst, "cycles_per_inst": 4, "simds": 1024,
-                          "clock_ghz": 2.4, "frac": n_inst * 4 / (1024 * dom_ms * 1e-3 * 2.4e9)}
+            cpi = dom_ms * 1e-3 * 2.4e9 * 1024 / n_inst
+            valu_issue = {"insts_per_launch": n_inst, "simds": 1024, "clock_ghz": 2.4,
+                          "cycles_per_inst": cpi, "dependent_chain_cycles_per_inst": 4.3,
+                          "independent_cycles_per_inst": 2.7, "frac_of_independent_rate": 2.7 / cpi}
 
     if rank == 0:
         line = {
