@@ -91,7 +91,7 @@ def _cpu_baseline_worker(sample_n: int):
     print(json.dumps({"dt": dt, "cores": cores}))
 
 
-def cpu_baseline(sample_n: int = 5_000, budget_s: float = 150.0):
+def cpu_baseline(sample_n: int = 250_000, budget_s: float = 150.0):
     """CPU oracle (a port: the reference has no CPU rasterizer, runner.py:153
     hard-codes cuda) timed on a bounded sample of the same workload, in a child
     process with a hard time budget so the default bench always finishes."""
