@@ -31,19 +31,20 @@ SIGNATURES = {
     "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
     "gsr_tile_sort": [_i, _p, _p, _p, _p, _p, _p],
     "gsr_bucket_layout": [_i, _i, _i, _p, _p],
-    "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _p],
-    "gsr_bucket_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
-    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "gsr_isect_scan_clear": [_i, _p, _p, _p, _p],
+    "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _i, _p],
+    "gsr_bucket_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _i, _p],
+    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
     "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
     "gsr_rasterize_bwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
 }
 SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_ssim_l1_bwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
-SIGNATURES["gsr_l1_fwd"] = [_i64, _p, _p, _p, _p]
-SIGNATURES["gsr_l1_bwd"] = [_i64, _p, _p, _p, _p, _p]
+SIGNATURES["gsr_l1_fwd"] = [_i64, _p, _p, _p, _p, _p]
+SIGNATURES["gsr_l1_bwd"] = [_i64, _p, _p, _p, _f, _p, _p]
 SIGNATURES["gsr_debug_tree_reduce8"] = [_p, _p, _p, _p]
-SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p]
+SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_project_bwd_adam"] = [_i, _i, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p, _p, _i, _i, _p,
                                       _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES["gsr_relocation"] = [_i, _p, _p, _p, _p, _i, _p, _p, _p]

@@ -61,8 +61,11 @@ __device__ __forceinline__ int order_bucket(int len) {
   return ORDER_BUCKETS - 1 - min(ORDER_BUCKETS - 1, (len + 31) >> 5);   // 0 = longest
 }
 
+// CLEAR: the counts are zeroed once they have been read (the bucketed builder reuses the
+// buffer as its emit cursor and keeps it across frames: no memset launches in between).
+template <bool CLEAR>
 __global__ void __launch_bounds__(1024)
-scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
+scan_kernel(int n, int32_t *__restrict__ in, int32_t *__restrict__ out,
             int32_t *__restrict__ tile_order) {
   __shared__ int32_t wave_tot[16];
   __shared__ int32_t carry_s;
@@ -102,7 +105,13 @@ scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
     __syncthreads();
   }
   if (tid == 0) out[n] = carry_s;
-  if (!tile_order) return;
+  if (!tile_order) {
+    if (CLEAR) {
+      __syncthreads();
+      for (int t = tid; t < n; t += 1024) in[t] = 0;
+    }
+    return;
+  }
   if (tid < ORDER_BUCKETS) hist[tid] = 0;
   __syncthreads();
   for (int t = tid; t < n; t += 1024) atomicAdd(&hist[order_bucket(in[t])], 1);
@@ -119,6 +128,10 @@ scan_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out,
   for (int t = tid; t < n; t += 1024) {
     int pos = atomicAdd(&hist[order_bucket(in[t])], 1);
     tile_order[pos] = t;
+  }
+  if (CLEAR) {
+    __syncthreads();
+    for (int t = tid; t < n; t += 1024) in[t] = 0;
   }
 }
 
@@ -246,9 +259,18 @@ extern "C" int gsr_isect_count(int C, int N, const float *means2d, const int32_t
 extern "C" int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets,
                               int32_t *tile_order, void *stream) {
   GSR_REQUIRE(n_tiles >= 0 && tile_counts && tile_offsets, "isect_scan: bad arguments");
-  hipLaunchKernelGGL(gsr::scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
-                     tile_counts, tile_offsets, tile_order);
+  hipLaunchKernelGGL(gsr::scan_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
+                     const_cast<int32_t *>(tile_counts), tile_offsets, tile_order);
   GSR_CHECK_LAUNCH("isect_scan");
+  return GSR_OK;
+}
+
+extern "C" int gsr_isect_scan_clear(int n, int32_t *counts, int32_t *offsets, int32_t *order,
+                                    void *stream) {
+  GSR_REQUIRE(n >= 0 && counts && offsets, "isect_scan_clear: bad arguments");
+  hipLaunchKernelGGL(gsr::scan_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, counts,
+                     offsets, order);
+  GSR_CHECK_LAUNCH("isect_scan_clear");
   return GSR_OK;
 }
 

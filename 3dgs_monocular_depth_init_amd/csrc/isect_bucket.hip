@@ -174,6 +174,40 @@ __device__ __forceinline__ void bk_bitonic_segments(uint64_t *seg, int L, int n_
   __syncthreads();
 }
 
+// tile order (longest list first, 64 length classes) from finished tile offsets, by ONE
+// workgroup of `nthreads` threads. (Doing this in the last-finishing workgroup of the sort
+// kernel instead of a launch of its own was tried: the device-scope fences it needs write
+// back the XCD's L2 in every workgroup and cost 0.33 ms.)
+constexpr int ORD_BUCKETS = 64;
+__device__ __forceinline__ void tile_order_body(int n, const int32_t *tile_offsets,
+                                                int32_t *__restrict__ tile_order, int tid,
+                                                int nthreads) {
+  __shared__ int32_t hist[ORD_BUCKETS];
+  auto ld = [&](int i) { return tile_offsets[i]; };
+  auto cls = [&](int t) {
+    const int len = ld(t + 1) - ld(t);
+    return ORD_BUCKETS - 1 - min(ORD_BUCKETS - 1, (len + 31) >> 5);
+  };
+  if (tid < ORD_BUCKETS) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += nthreads) atomicAdd(&hist[cls(t)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < ORD_BUCKETS; ++b) {
+      const int c = hist[b];
+      hist[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < n; t += nthreads) tile_order[atomicAdd(&hist[cls(t)], 1)] = t;
+}
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(int n, const int32_t *__restrict__ tile_offsets, int32_t *__restrict__ tile_order) {
+  tile_order_body(n, tile_offsets, tile_order, threadIdx.x, 1024);
+}
+
 // Pass 3: one workgroup per bucket. The keys are split by tile-in-bucket while they are
 // loaded into LDS (8-bin counting sort), then the 8 tile segments are depth-sorted side
 // by side, each by its own 128-thread group; flatten_ids and the tile offsets follow.
@@ -181,7 +215,7 @@ __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
                    const int32_t *__restrict__ bucket_order, uint64_t *__restrict__ keys,
                    int32_t *__restrict__ flatten_ids, int32_t *__restrict__ tile_offsets,
-                   int n_tiles, int capacity) {
+                   int n_tiles, int capacity, int32_t *__restrict__ clear_counts) {
   __shared__ uint64_t sk[BK_SORT_CAP];
   __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], seg_cur[BK_TILES], npad_max_s;
   const int tid = threadIdx.x;
@@ -241,34 +275,10 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     }
   }
   if (b == n_buckets - 1 && tid == 0) tile_offsets[n_tiles] = e;
+  if (clear_counts && tid == 0) clear_counts[b] = 0;   // the emit cursor of this bucket: zero for the next frame
 }
 
 // tile_order (longest list first) from finished tile offsets; one workgroup.
-constexpr int ORD_BUCKETS = 64;
-__global__ void __launch_bounds__(1024)
-tile_order_kernel(int n, const int32_t *__restrict__ tile_offsets, int32_t *__restrict__ tile_order) {
-  __shared__ int32_t hist[ORD_BUCKETS];
-  const int tid = threadIdx.x;
-  auto cls = [&](int t) {
-    const int len = tile_offsets[t + 1] - tile_offsets[t];
-    return ORD_BUCKETS - 1 - min(ORD_BUCKETS - 1, (len + 31) >> 5);
-  };
-  if (tid < ORD_BUCKETS) hist[tid] = 0;
-  __syncthreads();
-  for (int t = tid; t < n; t += 1024) atomicAdd(&hist[cls(t)], 1);
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int b = 0; b < ORD_BUCKETS; ++b) {
-      const int c = hist[b];
-      hist[b] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-  for (int t = tid; t < n; t += 1024) tile_order[atomicAdd(&hist[cls(t)], 1)] = t;
-}
-
 static inline int bk_grid(int64_t total, int64_t *chunk) {
   int g = (int)ceil_div64(total, 4096);
   if (g > 256) g = 256;
@@ -287,7 +297,8 @@ extern "C" int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int
 }
 
 extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii,
-                                int tile_w, int tile_h, int32_t *bucket_counts, void *stream) {
+                                int tile_w, int tile_h, int32_t *bucket_counts, int assume_zero,
+                                void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && bucket_counts, "bucket_count: bad arguments");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -295,7 +306,7 @@ extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_
     return GSR_ECAPACITY;
   }
   GSR_REQUIRE((int64_t)C * N < (1LL << 30), "bucket_count: C*N must be < 2^30 (composite key)");
-  if (nb > 0)
+  if (nb > 0 && !assume_zero)
     GSR_CHECK_HIP(hipMemsetAsync(bucket_counts, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
   const int64_t total = (int64_t)C * N;
   if (total == 0 || nb == 0) return GSR_OK;
@@ -312,7 +323,7 @@ extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_
 extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii,
                                const float *depths, int tile_w, int tile_h,
                                const int32_t *bucket_offsets, int32_t *bucket_cursor,
-                               uint64_t *keys, int64_t capacity, void *stream) {
+                               uint64_t *keys, int64_t capacity, int assume_zero, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && capacity >= 0, "bucket_emit: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -323,7 +334,8 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
   if (total == 0 || nb == 0) return GSR_OK;
   GSR_REQUIRE(means2d && radii && depths && bucket_offsets && bucket_cursor && (keys || capacity == 0),
               "bucket_emit: null pointer");
-  GSR_CHECK_HIP(hipMemsetAsync(bucket_cursor, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+  if (!assume_zero)
+    GSR_CHECK_HIP(hipMemsetAsync(bucket_cursor, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
   int64_t chunk;
   const int grid = gsr::bk_grid(total, &chunk);
   hipLaunchKernelGGL(gsr::bucket_emit_kernel, dim3(grid), dim3(gsr::BK_THREADS),
@@ -336,7 +348,7 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
 extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
                                const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
                                int32_t *tile_offsets, int32_t *tile_order, int64_t capacity,
-                               void *stream) {
+                               int32_t *clear_counts, void *stream) {
   GSR_REQUIRE(C >= 0 && tile_w > 0 && tile_h > 0, "bucket_sort: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -349,7 +361,7 @@ extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *buc
   hipLaunchKernelGGL(gsr::bucket_sort_kernel, dim3(nb), dim3(gsr::BK_THREADS), 0,
                      (hipStream_t)stream, nb, tile_w, bw, bucket_offsets, bucket_order, keys,
                      flatten_ids, tile_offsets, n_tiles,
-                     (int)(capacity < 2147483647LL ? capacity : 2147483647LL));
+                     (int)(capacity < 2147483647LL ? capacity : 2147483647LL), clear_counts);
   GSR_CHECK_LAUNCH("bucket_sort");
   if (tile_order) {
     hipLaunchKernelGGL(gsr::tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,

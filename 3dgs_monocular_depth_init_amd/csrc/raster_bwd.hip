@@ -92,7 +92,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
       const int64_t pix = ((int64_t)cam * height + y) * width + x;
       last[q] = last_ids[pix];
       T[q] = 1.0f - render_alphas[pix];
-      float kk = v_render_alphas[pix];
+      float kk = v_render_alphas ? v_render_alphas[pix] : 0.f;
 #pragma unroll
       for (int k = 0; k < CH; ++k) vout[q][k] = v_render_colors[pix * CH + k];
       if (backgrounds) {
@@ -350,8 +350,7 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
               "rasterize_bwd: tile grid does not match image");
   GSR_REQUIRE(CH >= 1 && CH <= 5, "rasterize_bwd: CH=%d", CH);
   if (C == 0) return GSR_OK;
-  GSR_REQUIRE(tile_offsets && render_alphas && last_ids && v_render_colors && v_render_alphas &&
-                  grad_rows,
+  GSR_REQUIRE(tile_offsets && render_alphas && last_ids && v_render_colors && grad_rows,
               "rasterize_bwd: null pointer");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;

@@ -199,7 +199,7 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
 // Plain L1 (runner.py:506 with ssim_lambda = 0): contiguous buffers, 16 B per lane.
 __global__ void __launch_bounds__(256)
 l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
-              double *__restrict__ sum) {
+              double *__restrict__ ws, float *__restrict__ mean_out) {
   // fp32 partial per thread (a few dozen terms of magnitude <= 1), fp64 across threads.
   // Few, fat workgroups: the kernel ends with one same-address fp64 atomic per workgroup
   // and those serialise at the memory side (2048 of them cost more than the 50 MB read),
@@ -226,12 +226,27 @@ l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ 
   double acc = wave_sum_f64((double)part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+  // ws[0] = running sum, ws[1] = workgroups done (both zero on entry). The last workgroup
+  // writes the mean and leaves the workspace zero again: no memset launch before, no
+  // elementwise launches after. No fence: device-scope float atomics execute at the memory
+  // side, and the data dependence (the ticket increment carries the returned old sum) orders
+  // a workgroup's two atomics; a fence here would write back the XCD's whole L2.
+  if (threadIdx.x == 0) {
+    const double prev = atomicAdd(&ws[0], red[0] + red[1] + red[2] + red[3]);
+    const double one = (prev == prev) ? 1.0 : 1.0 + prev;          // depends on prev, always 1
+    const double done = atomicAdd(&ws[1], one);
+    if (done == (double)(gridDim.x - 1)) {
+      const double total = atomicAdd(&ws[0], 0.0);
+      mean_out[0] = (float)(total / (double)n);
+      __hip_atomic_store(&ws[0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ws[1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 __global__ void __launch_bounds__(256)
 l1_bwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
-              const float *__restrict__ weight, float *__restrict__ grad) {
-  const float w = weight[0];
+              const float *__restrict__ upstream, float scale, float *__restrict__ grad) {
+  const float w = (upstream ? upstream[0] : 1.0f) * scale;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   auto sg = [w](float d) { return d > 0.f ? w : (d < 0.f ? -w : 0.f); };
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -248,27 +263,26 @@ l1_bwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ 
 
 }  // namespace gsr
 
-extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *sum, void *stream) {
-  GSR_REQUIRE(n >= 0 && a && b && sum, "l1_fwd: bad arguments");
+extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *workspace,
+                          float *mean_out, void *stream) {
+  GSR_REQUIRE(n > 0 && a && b && workspace && mean_out, "l1_fwd: bad arguments");
   GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "l1_fwd: buffers must be 16-byte aligned");
-  GSR_CHECK_HIP(hipMemsetAsync(sum, 0, sizeof(double), (hipStream_t)stream));
-  if (n == 0) return GSR_OK;
   int blocks = (int)(gsr::ceil_div64(n, 4096) < 512 ? gsr::ceil_div64(n, 4096) : 512);
   hipLaunchKernelGGL(gsr::l1_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
-                     sum);
+                     workspace, mean_out);
   GSR_CHECK_LAUNCH("l1_fwd");
   return GSR_OK;
 }
 
-extern "C" int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *weight,
-                          float *grad, void *stream) {
-  GSR_REQUIRE(n >= 0 && a && b && weight && grad, "l1_bwd: bad arguments");
+extern "C" int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *upstream,
+                          float scale, float *grad, void *stream) {
+  GSR_REQUIRE(n >= 0 && a && b && grad, "l1_bwd: bad arguments");
   GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad) % 16 == 0,
               "l1_bwd: buffers must be 16-byte aligned");
   if (n == 0) return GSR_OK;
   int blocks = (int)(gsr::ceil_div64(n, 1024) < 2048 ? gsr::ceil_div64(n, 1024) : 2048);
   hipLaunchKernelGGL(gsr::l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
-                     weight, grad);
+                     upstream, scale, grad);
   GSR_CHECK_LAUNCH("l1_bwd");
   return GSR_OK;
 }

@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
 // for `viewmats = inv(camtoworlds)` (runner.py:347) and for the camera
 // positions the SH view directions need.
 __global__ void inverse4x4_kernel(int C, const float *__restrict__ in, float *__restrict__ out,
-                                  float *__restrict__ in_translation) {
+                                  float *__restrict__ in_translation,
+                                  float *__restrict__ out_translation) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double m[16], inv[16];
@@ -99,6 +100,11 @@ __global__ void inverse4x4_kernel(int C, const float *__restrict__ in, float *__
     in_translation[c * 3 + 0] = in[c * 16 + 3];
     in_translation[c * 3 + 1] = in[c * 16 + 7];
     in_translation[c * 3 + 2] = in[c * 16 + 11];
+  }
+  if (out_translation) {
+    out_translation[c * 3 + 0] = (float)(inv[3] * idet);
+    out_translation[c * 3 + 1] = (float)(inv[7] * idet);
+    out_translation[c * 3 + 2] = (float)(inv[11] * idet);
   }
 }
 
@@ -182,12 +188,12 @@ extern "C" int gsr_inject_noise(int N, float *means, const float *quats, const f
 }
 
 extern "C" int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation,
-                              void *stream) {
+                              float *out_translation, void *stream) {
   GSR_REQUIRE(C >= 0, "inverse4x4: bad C");
   if (C == 0) return GSR_OK;
   GSR_REQUIRE(in && out, "inverse4x4: null pointer");
   hipLaunchKernelGGL(gsr::inverse4x4_kernel, dim3(gsr::ceil_div(C, 64)), dim3(64), 0,
-                     (hipStream_t)stream, C, in, out, in_translation);
+                     (hipStream_t)stream, C, in, out, in_translation, out_translation);
   GSR_CHECK_LAUNCH("inverse4x4");
   return GSR_OK;
 }

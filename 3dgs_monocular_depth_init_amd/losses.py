@@ -65,22 +65,31 @@ class _SsimL1(torch.autograd.Function):
         return grad, None, None, None
 
 
+_L1_WS = {}      # device index -> 2 zeroed doubles the forward kernel leaves zero again
+
+
 class _L1(torch.autograd.Function):
-    """mean |a - b| over contiguous buffers: one launch forward, one backward."""
+    """mean |a - b| over contiguous buffers: one launch forward, one backward, no
+    elementwise launches around them (the kernel finalises the mean itself and takes the
+    upstream gradient as a device scalar)."""
 
     @staticmethod
     def forward(ctx, a: Tensor, b: Tensor):
-        s = torch.empty(1, dtype=torch.float64, device=a.device)
-        call("gsr_l1_fwd", a.numel(), ptr(a), ptr(b), ptr(s), _st())
+        ws = _L1_WS.get(a.device.index)
+        if ws is None:
+            ws = _L1_WS[a.device.index] = torch.zeros(2, dtype=torch.float64, device=a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        call("gsr_l1_fwd", a.numel(), ptr(a), ptr(b), ptr(ws), ptr(out), _st())
         ctx.save_for_backward(a, b)
-        return (s[0] / a.numel()).float()
+        return out
 
     @staticmethod
     def backward(ctx, v):
         a, b = ctx.saved_tensors
-        w = (v / a.numel()).float().reshape(1).contiguous()
+        if v.dtype != torch.float32 or not v.is_cuda:
+            v = v.to(device=a.device, dtype=torch.float32)
         grad = torch.empty_like(a)
-        call("gsr_l1_bwd", a.numel(), ptr(a), ptr(b), ptr(w), ptr(grad), _st())
+        call("gsr_l1_bwd", a.numel(), ptr(a), ptr(b), ptr(v), 1.0 / a.numel(), ptr(grad), _st())
         return grad, None
 
 

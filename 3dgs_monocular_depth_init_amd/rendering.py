@@ -300,14 +300,19 @@ def _rows_from_grads(C: int, N: int, v_means2d, v_conics, v_colors, color_stride
 
 
 @torch.no_grad()
-def inverse4x4(mats: Tensor) -> Tuple[Tensor, Tensor]:
-    """Batched 4x4 inverse on the device in one launch. Returns (inverse [C,4,4],
-    translation column of the INVERSE [C,3])."""
+def inverse4x4(mats: Tensor, translation_of: str = "inverse") -> Tuple[Tensor, Tensor]:
+    """Batched 4x4 inverse on the device in ONE launch. Returns (inverse [C,4,4],
+    translation column [C,3] of the inverse or of the input): either way the camera
+    positions, for world-to-camera or camera-to-world input."""
     mats = _f32c(mats)
     C = mats.shape[0]
     out = torch.empty_like(mats)
-    call("gsr_inverse4x4", C, ptr(mats), ptr(out), None, _stream())
-    return out, out[:, :3, 3].contiguous()
+    tr = torch.empty(C, 3, dtype=torch.float32, device=mats.device)
+    if translation_of == "input":
+        call("gsr_inverse4x4", C, ptr(mats), ptr(out), ptr(tr), None, _stream())
+    else:
+        call("gsr_inverse4x4", C, ptr(mats), ptr(out), None, ptr(tr), _stream())
+    return out, tr
 
 
 # --------------------------------------------------------------------------- #
@@ -361,6 +366,9 @@ class _IsectState:
     GPU has work queued; an overflowing frame is simply rebuilt with larger buffers)."""
     capacity: Dict[int, int] = {}
     pinned: Dict[int, Tensor] = {}       # one reusable pinned int32 per device
+    # (device, n_buckets) -> bucket counts / emit cursor [n_buckets]: zero between frames
+    # (the scan and sort kernels clear it), so no memset launches
+    scratch: Dict[Tuple[int, int], Tensor] = {}
 
 
 class _PendingIsect:
@@ -385,11 +393,17 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
     n_tiles = C * tile_w * tile_h
     n_buckets = C * tile_h * ((tile_w + 7) // 8)
     st = _stream()
-    counts = torch.empty(n_buckets, dtype=torch.int32, device=dev)
+    key = (dev.index, n_buckets)
+    if capacity is None:                     # blocking path (first frame, overflow rebuild)
+        _IsectState.scratch.pop(key, None)   # fresh buffers; a failed frame may have left them dirty
+    sc = _IsectState.scratch.get(key)
+    if sc is None:
+        sc = _IsectState.scratch[key] = torch.zeros(n_buckets, dtype=torch.int32, device=dev)
+    counts = sc
     offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
     order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
-    call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), st)
-    call("gsr_isect_scan", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
+    call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), 1, st)
+    call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
     pending = None
     if capacity is None:
         n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
@@ -409,9 +423,9 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
     tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
-         ptr(offsets), ptr(counts), ptr(keys), cap, st)
+         ptr(offsets), ptr(counts), ptr(keys), cap, 1, st)
     call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
-         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, st)
+         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, ptr(counts), st)
     if pending is None:
         return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
     return tile_offsets, tile_order, flatten_ids, keys, pending
@@ -445,6 +459,9 @@ class _Rasterize(torch.autograd.Function):
         ctx.save_for_backward(means2d, backgrounds, tile_offsets, tile_order, flatten_ids,
                               render_alphas, last_ids, records)
         ctx.mark_non_differentiable(last_ids)
+        # unused outputs (the alphas under a colour-only loss) arrive as None in backward
+        # instead of freshly filled zero tensors: two fill launches less per step
+        ctx.set_materialize_grads(False)
         return render_colors, render_alphas, last_ids
 
     @staticmethod
@@ -456,10 +473,9 @@ class _Rasterize(torch.autograd.Function):
         dev = means2d.device
         if v_render_colors is None:
             v_render_colors = torch.zeros(C, height, width, CH, dtype=torch.float32, device=dev)
-        if v_render_alphas is None:
-            v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
         v_render_colors = _f32c(v_render_colors)
-        v_render_alphas = _f32c(v_render_alphas)
+        if v_render_alphas is not None:          # None: the kernel takes a null pointer as zeros
+            v_render_alphas = _f32c(v_render_alphas)
         rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
         call("gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
              tile_h, ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_alphas),

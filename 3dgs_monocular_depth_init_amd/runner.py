@@ -120,8 +120,7 @@ def rasterize_splats(
     rasterize_mode = "antialiased" if cfg.antialiased else "classic"
     # runner.py:324-325 (exp / sigmoid) run inside the projection kernels, and
     # runner.py:347 `torch.linalg.inv(camtoworlds)` is one small launch
-    viewmats, _ = inverse4x4(camtoworlds)
-    campos = camtoworlds[:, :3, 3].float().contiguous()
+    viewmats, campos = inverse4x4(camtoworlds, translation_of="input")   # + camera positions, one launch
     render_colors, render_alphas, info = rasterization(
         means=means, quats=quats, scales=splats["scales"], opacities=splats["opacities"],
         colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
@@ -132,6 +131,9 @@ def rasterize_splats(
     if masks is not None:
         render_colors[~masks] = 0
     return render_colors, render_alphas, info
+
+
+_ONES: Dict = {}     # device -> cached scalar 1.0, the root gradient of loss.backward()
 
 
 def train_step(
@@ -171,7 +173,11 @@ def train_step(
         loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
     if scale_reg > 0.0:                                                  # runner.py:540-545
         loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
-    loss.backward()                                                      # runner.py:547
+    one = _ONES.get(loss.device)
+    if one is None:
+        one = _ONES[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one if one.dtype == loss.dtype else None)              # runner.py:547 (root
+    # gradient handed over instead of a ones_like + fill launch per step)
     if grad_sync is not None:
         grad_sync()
     if strategy is not None:                                             # runner.py:639-658

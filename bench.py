@@ -169,7 +169,7 @@ def main():
         splats["sh0"].copy_(sc["sh0"].to(dev))
     optimizers = distributed.fuse_optimizers(splats, optimizers)
     vms, Ks = scenes.cameras(range(N_CAMS), width=WIDTH, height=HEIGHT)
-    c2ws = torch.linalg.inv(vms).to(dev)
+    c2ws = torch.linalg.inv(vms).contiguous().to(dev)   # (linalg.inv returns column-major batches)
     Ks = Ks.to(dev)
     gen = torch.Generator().manual_seed(2)
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]

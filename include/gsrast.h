@@ -139,6 +139,8 @@ int gsr_isect_count(int C, int N, const float *means2d, const int32_t *radii, in
                     void *stream);
 int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets,
                    int32_t *tile_order /* [n_tiles] or NULL */, void *stream);
+/* Same scan; the counts are zeroed once read (buffer reused as a cursor, kept across frames). */
+int gsr_isect_scan_clear(int n, int32_t *counts, int32_t *offsets, int32_t *order, void *stream);
 int gsr_isect_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                    int tile_w, int tile_h, const int32_t *tile_offsets, int32_t *tile_cursor,
                    uint64_t *isect_keys, int64_t capacity, void *stream);
@@ -168,14 +170,19 @@ int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
  *                       tile_offsets[n_tiles+1] and (optional) tile_order[n_tiles]. */
 int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int *n_buckets_out);
 int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_w,
-                     int tile_h, int32_t *bucket_counts, void *stream);
+                     int tile_h, int32_t *bucket_counts,
+                     int assume_zero /* 1: bucket_counts is already zero, no memset launch */,
+                     void *stream);
 int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                     int tile_w, int tile_h, const int32_t *bucket_offsets, int32_t *bucket_cursor,
-                    uint64_t *keys, int64_t capacity, void *stream);
+                    uint64_t *keys, int64_t capacity, int assume_zero /* cursor already zero */,
+                    void *stream);
 int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
                     const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
                     int32_t *tile_offsets, int32_t *tile_order,
                     int64_t capacity /* entries in keys / flatten_ids; offsets are clamped to it */,
+                    int32_t *clear_counts /* NULL, or [n_buckets]: zeroed per bucket on the way out
+                                             (a count / cursor buffer kept across frames) */,
                     void *stream);
 
 /* Compositing reads ONE packed 64-byte record per (camera, Gaussian):
@@ -195,7 +202,9 @@ int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrou
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *flatten_ids,
                       const float *render_alphas, const int32_t *last_ids,
-                      const float *v_render_colors, const float *v_render_alphas, int absgrad,
+                      const float *v_render_colors,
+                      const float *v_render_alphas /* NULL = no gradient on the alphas */,
+                      int absgrad,
                       float *grad_rows /* [C*N,16], zeroed by caller, accumulated */, void *stream);
 
 /* ---------------------------------------------------------------------------
@@ -231,11 +240,15 @@ int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1, const int64_
                     const float *dm_s1, const float *dm_s12, const float *weights, float *grad,
                     const int64_t *stridesg, void *stream);
 
-/* Plain L1 over n contiguous floats (16-byte aligned): sum |a-b| into a device
- * fp64 (zeroed inside); grad = weight[0] * sign(a-b), weight a device float. */
-int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *sum, void *stream);
-int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *weight, float *grad,
+/* Plain L1 over n contiguous floats (16-byte aligned), ONE launch each way:
+ * gsr_l1_fwd: mean_out[0] (device float) = mean |a-b|. workspace = 2 device doubles that are
+ *   zero on entry and left zero on exit (allocate and zero once, reuse every step).
+ * gsr_l1_bwd: grad = (upstream ? upstream[0] : 1) * scale * sign(a-b); upstream is the device
+ *   scalar autograd hands the loss, scale = 1/n. */
+int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *workspace, float *mean_out,
                void *stream);
+int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *upstream, float scale,
+               float *grad, void *stream);
 
 /* Test hook: in [8][64] -> out[0..63] = per-lane result of the 8-value lane-swap
  * reduction tree used by gsr_rasterize_bwd, out[64..127] = wave sum of in[0],
@@ -243,10 +256,11 @@ int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *weight, f
 int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_out, void *stream);
 
 /* Batched inverse of C row-major 4x4 matrices (viewmats = inv(camtoworlds),
- * gs_init_compare/runner.py:347). in_translation [C,3] (optional) receives the
- * translation column of the INPUT (the camera position when `in` is
- * camera-to-world). */
-int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation, void *stream);
+ * gs_init_compare/runner.py:347). in_translation / out_translation [C,3] (optional) receive
+ * the translation column of the INPUT / of the INVERSE: the camera positions when `in` is
+ * camera-to-world / world-to-camera. */
+int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation,
+                   float *out_translation, void *stream);
 
 /* MCMC densification strategy (the reference drives gsplat's MCMCStrategy at
  * gs_init_compare/runner.py:214-215, 649-658 with the "mcmc" preset of trainer.py:83-92).
