@@ -47,7 +47,7 @@ __device__ __forceinline__ float ld(const float *p, const ImgView &v, int n, int
 __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
                 const float *__restrict__ img2, ImgView v2, int valid_only,
-                double *__restrict__ sums, float *__restrict__ dm_mu1,
+                double *__restrict__ ws, float *__restrict__ dm_mu1,
                 float *__restrict__ dm_s1, float *__restrict__ dm_s12) {
   __shared__ float sX[SSIM_H][SSIM_H + 1];
   __shared__ float sY[SSIM_H][SSIM_H + 1];
@@ -123,9 +123,43 @@ ssim_fwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
     red[1][tid >> 6] = acc_l1;
   }
   __syncthreads();
+  // One pair of partial sums per workgroup, plain stores: thousands of workgroups adding
+  // into the same two addresses serialise at the memory side (measured: most of the kernel).
   if (tid == 0) {
-    atomicAdd(&sums[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(&sums[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    ws[2 * wg + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ws[2 * wg + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+// out[0] = mean SSIM, out[1] = mean |x-y|, out[2] = the reference's loss
+// (1-lambda)*L1 + lambda*(1-SSIM) (runner.py:506-510) from the per-workgroup partials.
+__global__ void __launch_bounds__(1024)
+ssim_finalize_kernel(int n_wg, const double *__restrict__ ws, float *__restrict__ out,
+                     double inv_n_ssim, double inv_n_l1, float ssim_lambda) {
+  __shared__ double red[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n_wg; i += 1024) {
+    a += ws[2 * i];
+    b += ws[2 * i + 1];
+  }
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      sa += red[0][w];
+      sb += red[1][w];
+    }
+    const double ssim = sa * inv_n_ssim, l1 = sb * inv_n_l1;
+    out[0] = (float)ssim;
+    out[1] = (float)l1;
+    out[2] = (float)(l1 * (1.0 - (double)ssim_lambda) + (1.0 - ssim) * (double)ssim_lambda);
   }
 }
 
@@ -135,7 +169,9 @@ __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
                 const float *__restrict__ img2, ImgView v2, const float *__restrict__ dm_mu1,
                 const float *__restrict__ dm_s1, const float *__restrict__ dm_s12,
-                const float *__restrict__ weights /* device [2]: w_ssim, w_l1 */,
+                const float *__restrict__ weights /* device [2]: w_ssim, w_l1, or NULL */,
+                const float *__restrict__ upstream /* device scalar (with weights NULL) */,
+                float scale_ssim, float scale_l1,
                 float *__restrict__ grad, ImgView vg) {
   __shared__ float sM[3][SSIM_H][SSIM_H + 1];
   __shared__ float sHz[3][SSIM_H][SSIM_T + 1];
@@ -144,7 +180,9 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
   const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
   const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
   const int x0 = bx * SSIM_T - SSIM_R, y0 = by * SSIM_T - SSIM_R;
-  const float w_ssim = weights[0], w_l1 = weights[1];
+  const float up = upstream ? upstream[0] : 1.0f;
+  const float w_ssim = weights ? weights[0] : up * scale_ssim;
+  const float w_l1 = weights ? weights[1] : up * scale_l1;
   for (int i = tid; i < SSIM_H * SSIM_H; i += 256) {
     const int ly = i / SSIM_H, lx = i % SSIM_H;
     const int gx = x0 + lx, gy = y0 + ly;
@@ -289,36 +327,49 @@ extern "C" int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float
 
 // img strides are in ELEMENTS for a logical [N, CH, H, W] image (pass the
 // strides of an NHWC tensor permuted to NCHW to consume it in place).
-// sums[2] (device, fp64, zeroed inside) = {sum of SSIM over the counted region,
-// sum |img1-img2| over all pixels}. dm_* [N,CH,H,W] may be NULL (no backward).
+// out[3] (device float) = {mean SSIM over the counted region, mean |img1-img2| over all
+// pixels, (1-lambda)*L1 + lambda*(1-SSIM)}; workspace = 2 device doubles per workgroup
+// (gsr_ssim_workspace_doubles), any content. dm_* [N,CH,H,W] may be NULL (no backward).
+extern "C" int64_t gsr_ssim_workspace_doubles(int N, int CH, int H, int W) {
+  return 2 * (int64_t)gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T) * N * CH;
+}
 extern "C" int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1,
                                const int64_t *strides1, const float *img2,
-                               const int64_t *strides2, int valid_only, double *sums,
-                               float *dm_mu1, float *dm_s1, float *dm_s12, void *stream) {
+                               const int64_t *strides2, int valid_only, double *workspace,
+                               float *out, float ssim_lambda, float *dm_mu1, float *dm_s1,
+                               float *dm_s12, void *stream) {
   GSR_REQUIRE(N > 0 && CH > 0 && H > 0 && W > 0, "ssim_l1_fwd: bad sizes");
-  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && sums, "ssim_l1_fwd: null pointer");
+  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && workspace && out, "ssim_l1_fwd: null pointer");
   GSR_REQUIRE((dm_mu1 == nullptr) == (dm_s1 == nullptr) && (dm_s1 == nullptr) == (dm_s12 == nullptr),
               "ssim_l1_fwd: pass all three derivative maps or none");
   GSR_REQUIRE((int64_t)N * CH < 65536, "ssim_l1_fwd: too many planes");
-  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(double), (hipStream_t)stream));
+  const int hh = valid_only ? H - 10 : H, ww = valid_only ? W - 10 : W;
+  const double n_ssim = (double)N * CH * (hh > 0 ? hh : 0) * (ww > 0 ? ww : 0);
+  const double n_l1 = (double)N * CH * H * W;
   gsr::ImgView v1{strides1[0], strides1[1], strides1[2], strides1[3]};
   gsr::ImgView v2{strides2[0], strides2[1], strides2[2], strides2[3]};
   dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
   hipLaunchKernelGGL(gsr::ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
-                     img1, v1, img2, v2, valid_only, sums, dm_mu1, dm_s1, dm_s12);
+                     img1, v1, img2, v2, valid_only, workspace, dm_mu1, dm_s1, dm_s12);
+  GSR_CHECK_LAUNCH("ssim_l1_fwd");
+  hipLaunchKernelGGL(gsr::ssim_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                     (int)(grid.x * grid.y), workspace, out, 1.0 / (n_ssim > 0 ? n_ssim : 1.0),
+                     1.0 / n_l1, ssim_lambda);
   GSR_CHECK_LAUNCH("ssim_l1_fwd");
   return GSR_OK;
 }
 
-// grad (strides stridesg) = weights[1]*sign(img1-img2) + weights[0]*dSSIM/dimg1,
-// weights = device float[2] (so the upstream gradient never visits the host).
+// grad (strides stridesg) = w_l1*sign(img1-img2) + w_ssim*dSSIM/dimg1 with either
+// (w_ssim, w_l1) = weights[0..1] (device float[2]) or, weights NULL, = upstream[0] *
+// (scale_ssim, scale_l1): the upstream gradient is a device scalar and never visits the host.
 extern "C" int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1,
                                const int64_t *strides1, const float *img2,
                                const int64_t *strides2, const float *dm_mu1, const float *dm_s1,
-                               const float *dm_s12, const float *weights, float *grad,
+                               const float *dm_s12, const float *weights, const float *upstream,
+                               float scale_ssim, float scale_l1, float *grad,
                                const int64_t *stridesg, void *stream) {
   GSR_REQUIRE(N > 0 && CH > 0 && H > 0 && W > 0, "ssim_l1_bwd: bad sizes");
-  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && dm_mu1 && dm_s1 && dm_s12 && weights &&
+  GSR_REQUIRE(img1 && img2 && strides1 && strides2 && dm_mu1 && dm_s1 && dm_s12 &&
                   grad && stridesg,
               "ssim_l1_bwd: null pointer");
   GSR_REQUIRE((int64_t)N * CH < 65536, "ssim_l1_bwd: too many planes");
@@ -327,7 +378,8 @@ extern "C" int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1,
   gsr::ImgView vg{stridesg[0], stridesg[1], stridesg[2], stridesg[3]};
   dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
   hipLaunchKernelGGL(gsr::ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
-                     img1, v1, img2, v2, dm_mu1, dm_s1, dm_s12, weights, grad, vg);
+                     img1, v1, img2, v2, dm_mu1, dm_s1, dm_s12, weights, upstream, scale_ssim,
+                     scale_l1, grad, vg);
   GSR_CHECK_LAUNCH("ssim_l1_bwd");
   return GSR_OK;
 }

@@ -27,42 +27,59 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SSIM_WS = {}    # (device index, shape) -> per-workgroup partial sums of the forward
+
+
 class _SsimL1(torch.autograd.Function):
-    """Returns (mean SSIM over the counted region, mean |a-b|) for logical NCHW views."""
+    """Returns (mean SSIM over the counted region, mean |a-b|, (1-lam)*L1 + lam*(1-SSIM))
+    for logical NCHW views: one launch forward, one backward, no elementwise launches."""
 
     @staticmethod
-    def forward(ctx, img1: Tensor, img2: Tensor, valid: bool, train: bool):
+    def forward(ctx, img1: Tensor, img2: Tensor, valid: bool, train: bool, lam: float):
         N, CH, H, W = img1.shape
         dev = img1.device
-        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        ws = _SSIM_WS.get((dev.index, N, CH, H, W))
+        if ws is None:
+            n_ws = 2 * ((W + 31) // 32) * ((H + 31) // 32) * N * CH      # = gsr_ssim_workspace_doubles
+            ws = _SSIM_WS[(dev.index, N, CH, H, W)] = torch.empty(n_ws, dtype=torch.float64, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
         need = train and img1.requires_grad
         maps = torch.empty(3, N, CH, H, W, dtype=torch.float32, device=dev) if need else None
         call("gsr_ssim_l1_fwd", N, CH, H, W, ptr(img1), _strides(img1), ptr(img2), _strides(img2),
-             int(valid), ptr(sums), ptr(maps[0]) if need else None, ptr(maps[1]) if need else None,
-             ptr(maps[2]) if need else None, _st())
+             int(valid), ptr(ws), ptr(out), float(lam), ptr(maps[0]) if need else None,
+             ptr(maps[1]) if need else None, ptr(maps[2]) if need else None, _st())
         hh, ww = (H - 10, W - 10) if valid else (H, W)
-        n_ssim = N * CH * max(hh, 0) * max(ww, 0)
-        n_l1 = N * CH * H * W
-        ctx.counts = (n_ssim, n_l1)
+        ctx.counts = (max(N * CH * max(hh, 0) * max(ww, 0), 1), N * CH * H * W)
+        ctx.lam = float(lam)
         ctx.save_for_backward(img1, img2, maps)
-        out = sums / torch.tensor([max(n_ssim, 1), n_l1], dtype=torch.float64, device=dev)
-        return out[0].float(), out[1].float()
+        return out[0], out[1], out[2]
 
     @staticmethod
-    def backward(ctx, v_ssim, v_l1):
+    def backward(ctx, v_ssim, v_l1, v_loss):
         img1, img2, maps = ctx.saved_tensors
         if maps is None:
             raise RuntimeError("fused_ssim was called with train=False; no backward available")
         N, CH, H, W = img1.shape
         n_ssim, n_l1 = ctx.counts
+        lam = ctx.lam
         dev = img1.device
-        z = torch.zeros((), device=dev)
-        w = torch.stack([(v_ssim if v_ssim is not None else z) / max(n_ssim, 1),
-                         (v_l1 if v_l1 is not None else z) / n_l1]).float().contiguous()
         grad = torch.empty_strided(img1.shape, img1.stride(), dtype=torch.float32, device=dev)
+        live = [(v, k) for k, v in enumerate((v_ssim, v_l1, v_loss)) if v is not None]
+        w = up = None
+        s_ssim = s_l1 = 0.0
+        if len(live) == 1:          # the usual cases: only the loss, or only the SSIM, is used
+            up, k = live[0]
+            up = up if (up.dtype == torch.float32 and up.is_cuda) else up.to(dev, torch.float32)
+            s_ssim = (1.0 / n_ssim, 0.0, -lam / n_ssim)[k]
+            s_l1 = (0.0, 1.0 / n_l1, (1.0 - lam) / n_l1)[k]
+        else:                        # several outputs used at once: combine the weights on the device
+            z = torch.zeros((), device=dev)
+            vs, vl, vt = ((v if v is not None else z).float() for v in (v_ssim, v_l1, v_loss))
+            w = torch.stack([(vs - lam * vt) / n_ssim, (vl + (1.0 - lam) * vt) / n_l1]).contiguous()
         call("gsr_ssim_l1_bwd", N, CH, H, W, ptr(img1), _strides(img1), ptr(img2), _strides(img2),
-             ptr(maps[0]), ptr(maps[1]), ptr(maps[2]), ptr(w), ptr(grad), _strides(grad), _st())
-        return grad, None, None, None
+             ptr(maps[0]), ptr(maps[1]), ptr(maps[2]), ptr(w), ptr(up), s_ssim, s_l1, ptr(grad),
+             _strides(grad), _st())
+        return grad, None, None, None, None
 
 
 _L1_WS = {}      # device index -> 2 zeroed doubles the forward kernel leaves zero again
@@ -114,12 +131,12 @@ def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = 
     """Mean SSIM of NCHW images (drop-in for fused_ssim.fused_ssim, runner.py:507)."""
     assert padding in ("same", "valid")
     img1, img2 = _check(img1, img2)
-    ssim, _ = _SsimL1.apply(img1, img2.detach(), padding == "valid", train)
+    ssim, _, _ = _SsimL1.apply(img1, img2.detach(), padding == "valid", train, 0.0)
     return ssim
 
 
 def l1_ssim_loss(colors: Tensor, pixels: Tensor, ssim_lambda: float = 0.2) -> Tensor:
     """runner.py:506-510 fused: colors / pixels are NHWC [C,H,W,3]."""
     c, p = _check(colors.permute(0, 3, 1, 2), pixels.permute(0, 3, 1, 2))
-    ssim, l1 = _SsimL1.apply(c, p.detach(), True, True)
-    return l1 * (1.0 - ssim_lambda) + (1.0 - ssim) * ssim_lambda
+    _, _, loss = _SsimL1.apply(c, p.detach(), True, True, float(ssim_lambda))
+    return loss

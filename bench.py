@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=N_GAUSS)
+    ap.add_argument("--ssim-lambda", type=float, default=0.0,
+                    help="0 (default): the metric's L1 loss; 0.2: the reference's full loss (runner.py:506-510)")
     ap.add_argument("--separate-adam", action="store_true",
                     help="N=1: keep gsr_project_bwd and gsr_adam_step as two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -187,7 +189,7 @@ def main():
         cam = (k * world + rank) % N_CAMS
         _, info = runner.train_step(
             splats, None if args.no_optimizer else optimizers, c2ws[cam:cam + 1], Ks[cam:cam + 1],
-            targets[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync)
+            targets[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync, ssim_lambda=args.ssim_lambda)
         if args.no_optimizer:
             for p in splats.values():
                 p.grad = None
@@ -266,7 +268,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("c4: 1M-Gaussian seeded scene S(1e6,seed 0), 100 synthetic cameras "
-                             "1920x1080 f=1200, 1 view/rank/step, SH degree 3, L1 loss, full backward"
+                             "1920x1080 f=1200, 1 view/rank/step, SH degree 3, "
+                             + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
+                             + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
                              + (", RCCL all-reduce of 59N fp32 grads" if world > 1 else "")),
                 "gaussians": N, "visible": V, "n_isects": I, "pixels": P,

@@ -225,19 +225,25 @@ int gsr_adam_step(int n, void *const *params, const void *const *grads, void *co
  * third-party `fused_ssim`, setup.py:14). Images are logical [N,CH,H,W] fp32
  * addressed by ELEMENT strides (HOST int64[4]), so NHWC renders are used in
  * place. 11x11 Gaussian window (sigma 1.5), zero padding, C1=0.01^2, C2=0.03^2.
- * fwd: sums[2] (device fp64, zeroed inside) = {sum SSIM over the counted
- *      region (all pixels, or the map cropped by 5 px when valid_only),
- *      sum |img1-img2|}; dm_* [N,CH,H,W] receive dSSIM/d{mu1,sigma1^2,sigma12}
- *      (all three or all NULL).
- * bwd: grad = weights[1]*sign(img1-img2) + weights[0]*dSSIM/dimg1 with
- *      weights a device float[2].
+ * fwd: out[3] (device float) = {mean SSIM over the counted region (all pixels, or the map
+ *      cropped by 5 px when valid_only), mean |img1-img2|, the reference's loss
+ *      (1-ssim_lambda)*L1 + ssim_lambda*(1-SSIM) of runner.py:506-510}, finalised on the
+ *      device; workspace = gsr_ssim_workspace_doubles(N,CH,H,W) device doubles (per-workgroup
+ *      partial sums, any content on entry); dm_* [N,CH,H,W] receive
+ *      dSSIM/d{mu1,sigma1^2,sigma12} (all three or all NULL).
+ * bwd: grad = w_l1*sign(img1-img2) + w_ssim*dSSIM/dimg1, (w_ssim, w_l1) = weights[0..1]
+ *      (device float[2]) or, weights NULL, upstream[0] * (scale_ssim, scale_l1) with upstream
+ *      the device scalar autograd hands the loss (NULL = 1).
  * --------------------------------------------------------------------------*/
+int64_t gsr_ssim_workspace_doubles(int N, int CH, int H, int W);
 int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1, const int64_t *strides1,
-                    const float *img2, const int64_t *strides2, int valid_only, double *sums,
-                    float *dm_mu1, float *dm_s1, float *dm_s12, void *stream);
+                    const float *img2, const int64_t *strides2, int valid_only,
+                    double *workspace, float *out, float ssim_lambda, float *dm_mu1,
+                    float *dm_s1, float *dm_s12, void *stream);
 int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1, const int64_t *strides1,
                     const float *img2, const int64_t *strides2, const float *dm_mu1,
-                    const float *dm_s1, const float *dm_s12, const float *weights, float *grad,
+                    const float *dm_s1, const float *dm_s12, const float *weights,
+                    const float *upstream, float scale_ssim, float scale_l1, float *grad,
                     const int64_t *stridesg, void *stream);
 
 /* Plain L1 over n contiguous floats (16-byte aligned), ONE launch each way:
