@@ -158,7 +158,51 @@ inject_noise_kernel(int N, float *__restrict__ means, const float *__restrict__ 
     means[i * 3 + r] += cov.m[r][0] * nz[0] + cov.m[r][1] * nz[1] + cov.m[r][2] * nz[2];
 }
 
+// DefaultStrategy statistics (gsplat's DefaultStrategy._update_state, driven from
+// runner.py:639-647), one launch and no host sync instead of clone / scale / nonzero /
+// index_add / maximum: for every (camera, Gaussian) pair with both radii > 0,
+//   grad2d[i] += || (g.x * sx, g.y * sy) ||,  count[i] += 1,
+//   radii_state[i] = max(radii_state[i], max(rx, ry) / max_wh)      (optional)
+// g = means2d gradient of the pair, read with a row stride (it lives in the 64-byte rows).
+__global__ void __launch_bounds__(256)
+strategy_accumulate_kernel(int C, int N, const float *__restrict__ grad, int grad_stride,
+                           const int32_t *__restrict__ radii, float sx, float sy,
+                           float *__restrict__ grad2d, float *__restrict__ count,
+                           float *__restrict__ radii_state, float inv_max_wh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float acc = 0.f, cnt = 0.f, rmax = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const int64_t g = (int64_t)c * N + i;
+    const int rx = radii[g * 2], ry = radii[g * 2 + 1];
+    if (rx <= 0 || ry <= 0) continue;
+    const float gx = grad[g * grad_stride] * sx, gy = grad[g * grad_stride + 1] * sy;
+    acc += sqrtf(gx * gx + gy * gy);
+    cnt += 1.f;
+    rmax = fmaxf(rmax, (float)max(rx, ry) * inv_max_wh);
+  }
+  if (cnt > 0.f) {
+    grad2d[i] += acc;
+    count[i] += cnt;
+    if (radii_state) radii_state[i] = fmaxf(radii_state[i], rmax);
+  }
+}
+
 }  // namespace gsr
+
+extern "C" int gsr_strategy_accumulate(int C, int N, const float *grad, int grad_stride,
+                                       const int32_t *radii, float sx, float sy, float *grad2d,
+                                       float *count, float *radii_state, float max_wh,
+                                       void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && grad_stride >= 2 && max_wh > 0.f, "strategy_accumulate: bad sizes");
+  if ((int64_t)C * N == 0) return GSR_OK;
+  GSR_REQUIRE(grad && radii && grad2d && count, "strategy_accumulate: null pointer");
+  hipLaunchKernelGGL(gsr::strategy_accumulate_kernel, dim3(gsr::ceil_div(N, 256)), dim3(256), 0,
+                     (hipStream_t)stream, C, N, grad, grad_stride, radii, sx, sy, grad2d, count,
+                     radii_state, 1.0f / max_wh);
+  GSR_CHECK_LAUNCH("strategy_accumulate");
+  return GSR_OK;
+}
 
 extern "C" int gsr_relocation(int n, const float *opacities, const float *scales,
                               const int32_t *ratios, const float *binoms, int n_max,

@@ -185,24 +185,46 @@ class DefaultStrategy:
         for key in ("width", "height", "n_cameras", "radii", self.key_for_gradient):
             assert key in info, f"{key} is required but missing."
         m2d = info[self.key_for_gradient]
-        grads = (m2d.absgrad if self.absgrad else m2d.grad).clone()
-        grads[..., 0] *= info["width"] / 2.0 * info["n_cameras"]
-        grads[..., 1] *= info["height"] / 2.0 * info["n_cameras"]
+        g = m2d.absgrad if self.absgrad else m2d.grad
         n = len(params["means"])
-        dev = grads.device
+        dev = g.device
         if state["grad2d"] is None:
             state["grad2d"] = torch.zeros(n, device=dev)
             state["count"] = torch.zeros(n, device=dev)
         if self.refine_scale2d_stop_iter > 0 and state["radii"] is None:
             state["radii"] = torch.zeros(n, device=dev)
         radii = info["radii"]
+        sx = info["width"] / 2.0 * info["n_cameras"]
+        sy = info["height"] / 2.0 * info["n_cameras"]
+        max_wh = float(max(info["width"], info["height"]))
+        if g.is_cuda:
+            # one launch, no host sync (the torch formulation below needs a nonzero()); the
+            # screen-space radius statistic is the maximum over the cameras of the batch (the
+            # indexed assignment below keeps an arbitrary camera's value when C > 1)
+            C = radii.shape[0]
+            if g.dim() == 3 and g.stride(-1) == 1 and g.stride(0) == n * g.stride(1):
+                stride = g.stride(1)                 # dense (2) or the view into the 64-byte rows (16)
+            else:
+                g = g.contiguous()
+                stride = 2
+            rad = radii if radii.is_contiguous() else radii.contiguous()
+            rs = state["radii"] if self.refine_scale2d_stop_iter > 0 else None
+            _call()("gsr_strategy_accumulate", C, n, g.data_ptr(), stride, rad.data_ptr(), float(sx),
+                    float(sy), state["grad2d"].data_ptr(), state["count"].data_ptr(),
+                    rs.data_ptr() if rs is not None else None, max_wh,
+                    torch.cuda.current_stream().cuda_stream)
+            return
+        # host-side formulation (CPU tensors: the unit tests of the schedule and bookkeeping)
+        grads = g.clone()
+        grads[..., 0] *= sx
+        grads[..., 1] *= sy
         sel = (radii > 0).all(dim=-1)                       # [C,N]
         gs_ids = torch.where(sel)[1]
-        g = grads[sel]
-        state["grad2d"].index_add_(0, gs_ids, g.norm(dim=-1))
+        gsel = grads[sel]
+        state["grad2d"].index_add_(0, gs_ids, gsel.norm(dim=-1))
         state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
         if self.refine_scale2d_stop_iter > 0:
-            r = radii[sel].max(dim=-1).values.float() / float(max(info["width"], info["height"]))
+            r = radii[sel].max(dim=-1).values.float() / max_wh
             state["radii"][gs_ids] = torch.maximum(state["radii"][gs_ids], r)
 
     def _sync_state(self, state) -> None:

@@ -268,6 +268,18 @@ int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_out, void *
 int gsr_inverse4x4(int C, const float *in, float *out, float *in_translation,
                    float *out_translation, void *stream);
 
+/* DefaultStrategy statistics (gsplat's DefaultStrategy._update_state, which the
+ * reference drives at gs_init_compare/runner.py:639-647), one launch, no host sync: for every
+ * (camera, Gaussian) pair with both radii > 0
+ *   grad2d[i] += hypot(g.x*sx, g.y*sy);  count[i] += 1;
+ *   radii_state[i] = max(radii_state[i], max(rx, ry) / max_wh)          (radii_state may be NULL)
+ * with g the pair's means2d gradient at grad[(c*N+i)*grad_stride + {0,1}] (grad_stride = 2 for a
+ * dense [C,N,2] tensor, 16 for the view into the 64-byte gradient rows), sx = width/2*C,
+ * sy = height/2*C. */
+int gsr_strategy_accumulate(int C, int N, const float *grad, int grad_stride, const int32_t *radii,
+                            float sx, float sy, float *grad2d, float *count, float *radii_state,
+                            float max_wh, void *stream);
+
 /* MCMC densification strategy (the reference drives gsplat's MCMCStrategy at
  * gs_init_compare/runner.py:214-215, 649-658 with the "mcmc" preset of trainer.py:83-92).
  * gsr_relocation replaces gsplat's `compute_relocation` CUDA op: for i < n,
