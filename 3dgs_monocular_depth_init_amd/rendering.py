@@ -559,6 +559,8 @@ def rasterization(
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"rasterize_mode={rasterize_mode!r}")
     split_sh = isinstance(colors, (tuple, list))
+    if split_sh and sh_degree is None:
+        raise ValueError("colors=(sh0, shN) are spherical-harmonics coefficients: pass sh_degree")
     _check_cuda(means, quats, scales, opacities, viewmats, Ks, backgrounds,
                 *(colors if split_sh else (colors,)))
     _lib.load()

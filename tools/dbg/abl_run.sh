@@ -1,8 +1,8 @@
 #!/bin/bash
-# time the compositing kernels with each ablation build (tools/dbg/abl/lib_N.so)
+# time the step with each build variant (tools/dbg/abl/lib_NAME.so)
 for a in "$@"; do
-  GSRAST_LIB=$PWD/tools/dbg/abl/lib_$a.so python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+  GSRAST_LIB=$PWD/tools/dbg/abl/lib_$a.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_ms']
-print('abl $a', 'bwd', k['gsr_rasterize_bwd'], 'fwd', k['gsr_rasterize_fwd'], 'step', d['ms_per_step'])" || exit 1
+print('abl $a', 'pbwd_adam', k.get('gsr_project_bwd_adam'), 'bwd', k['gsr_rasterize_bwd'], 'fwd', k['gsr_rasterize_fwd'], 'step', round(d['ms_per_step'],4))" || exit 1
 done
