@@ -122,18 +122,19 @@ __device__ __forceinline__ void bk_bitonic(Ptr data, int L, int tid) {
   int n_pad = 1;
   while (n_pad < L) n_pad <<= 1;
   const int n_pairs = n_pad >> 1;
-  for (int k = 2; k <= n_pad; k <<= 1) {
-    const int half = k >> 1;
+  for (int lk = 1; (1 << lk) <= n_pad; ++lk) {
+    const int k = 1 << lk, lhalf = lk - 1;
     // mirror step: partners span the whole k-block
     for (int t = tid; t < n_pairs; t += BK_THREADS) {
-      const int blk = t / half, off = t - blk * half;
-      bk_cmpx(data, blk * k + off, blk * k + k - 1 - off, L);
+      const int blk = t >> lhalf, off = t & ((1 << lhalf) - 1);
+      bk_cmpx(data, (blk << lk) + off, (blk << lk) + k - 1 - off, L);
     }
     if (WAVE_LOCAL_OK && k <= 128) bk_wave_sync(); else __syncthreads();
-    for (int j = k >> 2; j >= 1; j >>= 1) {
+    for (int lj = lk - 2; lj >= 0; --lj) {
+      const int j = 1 << lj;
       for (int t = tid; t < n_pairs; t += BK_THREADS) {
-        const int blk = t / j, off = t - blk * j;
-        const int lo = 2 * j * blk + off;
+        const int blk = t >> lj, off = t & (j - 1);
+        const int lo = (blk << (lj + 1)) + off;
         bk_cmpx(data, lo, lo + j, L);
       }
       // wave-only ordering suffices iff THIS step and the NEXT one (stride j/2, or the next
@@ -152,19 +153,23 @@ __device__ __forceinline__ void bk_bitonic_segments(uint64_t *seg, int L, int n_
   int n_pad = 1;
   while (n_pad < L) n_pad <<= 1;
   const int n_pairs = n_pad >> 1;
-  for (int k = 2; k <= n_pad_max; k <<= 1) {
-    const int half = k >> 1;
+  // strides are powers of two: block / offset of a pair by shift and mask (a runtime integer
+  // division per compare-exchange cost more than the exchange itself)
+  for (int lk = 1; (1 << lk) <= n_pad_max; ++lk) {
+    const int k = 1 << lk, lhalf = lk - 1;
     if (k <= n_pad)
       for (int t = gtid; t < n_pairs; t += GT) {
-        const int blk = t / half, off = t - blk * half;
-        bk_cmpx(seg, blk * k + off, blk * k + k - 1 - off, L);
+        const int blk = t >> lhalf, off = t & ((1 << lhalf) - 1);
+        const int base = blk << lk;
+        bk_cmpx(seg, base + off, base + k - 1 - off, L);
       }
     if (k <= 128) bk_wave_sync(); else __syncthreads();
-    for (int j = k >> 2; j >= 1; j >>= 1) {
+    for (int lj = lk - 2; lj >= 0; --lj) {
+      const int j = 1 << lj;
       if (k <= n_pad)
         for (int t = gtid; t < n_pairs; t += GT) {
-          const int blk = t / j, off = t - blk * j;
-          const int lo = 2 * j * blk + off;
+          const int blk = t >> lj, off = t & (j - 1);
+          const int lo = (blk << (lj + 1)) + off;
           bk_cmpx(seg, lo, lo + j, L);
         }
       const bool both_local = (j > 1) ? (j <= 64) : (2 * k <= 128);
