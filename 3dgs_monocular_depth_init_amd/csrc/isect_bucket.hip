@@ -50,7 +50,7 @@ bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
   for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
     int x0, x1, y0, y1;
     if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h,
+    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h,
                     [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
   }
   __syncthreads();
@@ -74,7 +74,7 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
     int x0, x1, y0, y1;
     if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h,
+    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h,
                     [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
   }
   __syncthreads();
@@ -89,7 +89,7 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     int x0, x1, y0, y1;
     if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
     const float d = depths[g];
-    for_each_bucket((int)(g / N), x0, x1, y0, y1, bw, tile_h, [&](int b, int xa, int xb, int) {
+    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h, [&](int b, int xa, int xb, int) {
       const int n = xb - xa;
       const int64_t p = (int64_t)base[b] + atomicAdd(&hist[b], n);
       for (int k = 0; k < n; ++k)

@@ -45,7 +45,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    int32_t *__restrict__ tile_counts, float *__restrict__ records) {
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
-  int c = (int)(g / N);
+  int c = (C == 1) ? 0 : (int)(g / N);   // (64-bit division only with several cameras)
   int i = (int)(g - (int64_t)c * N);
   gs::Camera cam = gs::load_camera(viewmats + c * 16, Ks + c * 9);
   float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
