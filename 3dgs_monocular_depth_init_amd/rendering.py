@@ -400,32 +400,36 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
     if sc is None:
         sc = _IsectState.scratch[key] = torch.zeros(n_buckets, dtype=torch.int32, device=dev)
     counts = sc
-    offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
-    order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
-    call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), 1, st)
-    call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
-    pending = None
-    if capacity is None:
-        n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
-        cap = max(n_isects, 1)
-        _IsectState.capacity[dev.index] = int(n_isects * 1.25) + 8192
-    else:
-        n_host = _IsectState.pinned.get(dev.index)
-        if n_host is None:
-            n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        n_host.copy_(offsets[-1:], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        cap = max(int(capacity), 1)
-        pending = _PendingIsect(dev, n_host, ev, cap)
-    keys = torch.empty(cap, dtype=torch.int64, device=dev)
-    flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
-    tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-    tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
-    call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
-         ptr(offsets), ptr(counts), ptr(keys), cap, 1, st)
-    call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
-         ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, ptr(counts), st)
+    try:
+        offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
+        order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
+        call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), 1, st)
+        call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
+        pending = None
+        if capacity is None:
+            n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
+            cap = max(n_isects, 1)
+            _IsectState.capacity[dev.index] = int(n_isects * 1.25) + 8192
+        else:
+            n_host = _IsectState.pinned.get(dev.index)
+            if n_host is None:
+                n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            n_host.copy_(offsets[-1:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            cap = max(int(capacity), 1)
+            pending = _PendingIsect(dev, n_host, ev, cap)
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+        tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+        call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
+             ptr(offsets), ptr(counts), ptr(keys), cap, 1, st)
+        call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
+             ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, ptr(counts), st)
+    except BaseException:
+        _IsectState.scratch.pop(key, None)     # the kernels that clear it may not have run
+        raise
     if pending is None:
         return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
     return tile_offsets, tile_order, flatten_ids, keys, pending
