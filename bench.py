@@ -139,6 +139,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    # rehearsal knobs for a 1-GPU box: GSR_BENCH_SINGLE_DEVICE=1 puts every rank on device 0,
+    # GSR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("GSR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # GSR_BENCH_FORCE_DIST=1 (under torchrun with one rank) rehearses the whole RCCL
@@ -153,7 +158,10 @@ def main():
         sys.stdout.flush()
         json_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
     runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
