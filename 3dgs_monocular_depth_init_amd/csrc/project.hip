@@ -131,7 +131,8 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    int height, float eps2d, int sh_degree, const float *__restrict__ sh0,
                    int sh0_stride, const float *__restrict__ shN, int shN_stride,
                    const int32_t *__restrict__ radii, const float *__restrict__ grad_rows,
-                   const float *__restrict__ v_depths, const float *__restrict__ v_comps,
+                   int row_stride, const float *__restrict__ v_depths,
+                   const float *__restrict__ v_comps,
                    int depth_channel, float *__restrict__ v_means, float *__restrict__ v_quats,
                    float *__restrict__ v_scales, float *__restrict__ v_sh0, int v_sh0_stride,
                    float *__restrict__ v_shN, int v_shN_stride, int sh_K, int activations,
@@ -171,8 +172,10 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 
   for (int c = 0; c < C; ++c) {
     int64_t g = (int64_t)c * N + i;
-    if (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) continue;
-    const float *row = grad_rows + g * GSR_GRAD_ROW;
+    const float *row = grad_rows + g * row_stride;
+    // visibility: the radii of the pair, or (rows gathered from other ranks, packed by
+    // gsr_pack_grad_rows) the flag in slot GSR_PACKED_VIS of the row
+    if (radii ? (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) : (row[GSR_PACKED_VIS] == 0.f)) continue;
     v_op += row[GSR_GR_OPAC];
     float v_m2d[2] = {row[GSR_GR_MEAN2D], row[GSR_GR_MEAN2D + 1]};
     float v_con[3] = {row[GSR_GR_CONIC], row[GSR_GR_CONIC + 1], row[GSR_GR_CONIC + 2]};
@@ -417,11 +420,43 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
   dim3 grid((unsigned)gsr::ceil_div(N, 256));
   hipLaunchKernelGGL(gsr::project_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
                      means, quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree,
-                     sh0, sh0_stride, shN, shN_stride, radii, grad_rows, v_depths, v_compensations,
+                     sh0, sh0_stride, shN, shN_stride, radii, grad_rows, GSR_GRAD_ROW, v_depths,
+                     v_compensations,
                      depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
                      v_sh0_stride, v_shN, v_shN_stride, sh_K, activations, opacities_act,
                      v_opacities, gsr::AdamFused{});
   GSR_CHECK_LAUNCH("project_bwd");
+  return GSR_OK;
+}
+
+// Compact form of the gradient rows for the exchange between view-parallel ranks: the 9 used
+// floats of a 64-byte row + a visibility flag = 40 bytes per Gaussian (see gsr_pack_grad_rows).
+namespace gsr {
+__global__ void __launch_bounds__(256)
+pack_grad_rows_kernel(int64_t n, const float *__restrict__ rows, const int32_t *__restrict__ radii,
+                      float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool vis = radii[i * 2] > 0 && radii[i * 2 + 1] > 0;
+  const float4 a = *reinterpret_cast<const float4 *>(rows + i * GSR_GRAD_ROW);
+  const float4 b = *reinterpret_cast<const float4 *>(rows + i * GSR_GRAD_ROW + 4);
+  const float c = rows[i * GSR_GRAD_ROW + 8];
+  float *o = out + i * GSR_PACKED_ROW;
+  o[0] = vis ? a.x : 0.f; o[1] = vis ? a.y : 0.f; o[2] = vis ? a.z : 0.f; o[3] = vis ? a.w : 0.f;
+  o[4] = vis ? b.x : 0.f; o[5] = vis ? b.y : 0.f; o[6] = vis ? b.z : 0.f; o[7] = vis ? b.w : 0.f;
+  o[8] = vis ? c : 0.f;
+  o[GSR_PACKED_VIS] = vis ? 1.f : 0.f;
+}
+}  // namespace gsr
+
+extern "C" int gsr_pack_grad_rows(int64_t n, const float *grad_rows, const int32_t *radii,
+                                  float *packed, void *stream) {
+  GSR_REQUIRE(n >= 0, "pack_grad_rows: bad n");
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(grad_rows && radii && packed, "pack_grad_rows: null pointer");
+  hipLaunchKernelGGL(gsr::pack_grad_rows_kernel, dim3((unsigned)gsr::ceil_div64(n, 256)), dim3(256),
+                     0, (hipStream_t)stream, n, grad_rows, radii, packed);
+  GSR_CHECK_LAUNCH("pack_grad_rows");
   return GSR_OK;
 }
 
@@ -431,7 +466,8 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
 extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks,
                                     const float *campos, int width, int height, float eps2d,
                                     int sh_degree, const int32_t *radii, const float *grad_rows,
-                                    const float *v_depths, const float *v_compensations,
+                                    int grad_stride, const float *v_depths,
+                                    const float *v_compensations,
                                     int depth_channel, int activations, const float *opacities_act,
                                     void *const *params, void *const *exp_avg,
                                     void *const *exp_avg_sq, const float *step_size,
@@ -439,9 +475,13 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
                                     double eps_d, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd_adam: bad sizes");
   if (N == 0) return GSR_OK;
-  GSR_REQUIRE(viewmats && Ks && campos && radii && grad_rows && params && exp_avg && exp_avg_sq &&
+  GSR_REQUIRE(viewmats && Ks && campos && grad_rows && params && exp_avg && exp_avg_sq &&
                   step_size && bc2_sqrt,
               "project_bwd_adam: null pointer");
+  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW,
+              "project_bwd_adam: grad_stride %d (16 = scratch rows, 10 = packed rows)", grad_stride);
+  GSR_REQUIRE(radii || grad_stride == GSR_PACKED_ROW,
+              "project_bwd_adam: radii may be NULL only with packed rows (visibility flag in the row)");
   GSR_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_bwd_adam: sh_degree %d", sh_degree);
   GSR_REQUIRE(activations == (GSR_ACT_EXP_SCALES | GSR_ACT_SIGMOID_OPAC) && opacities_act,
               "project_bwd_adam: raw scales / raw opacities (fused activations) required");
@@ -463,7 +503,7 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
   hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
                      af.p[gsr::AF_MEANS], af.p[gsr::AF_QUATS], af.p[gsr::AF_SCALES], viewmats, Ks,
                      campos, width, height, eps2d, sh_degree, af.p[gsr::AF_SH0], 3,
-                     af.p[gsr::AF_SHN], 45, radii, grad_rows, v_depths, v_compensations,
+                     af.p[gsr::AF_SHN], 45, radii, grad_rows, grad_stride, v_depths, v_compensations,
                      depth_channel, nullptr, nullptr, nullptr, nullptr, 3, nullptr, 45, 16,
                      activations, opacities_act, nullptr, af);
   GSR_CHECK_LAUNCH("project_bwd_adam");

@@ -27,6 +27,7 @@ from ._lib import call, ptr
 
 TILE = 16
 GRAD_ROW = 16
+PACKED_ROW = 10                                # GSR_PACKED_ROW
 ACT_EXP_SCALES, ACT_SIGMOID_OPAC = 1, 2      # GSR_ACT_* of include/gsrast.h
 GR_MEAN2D, GR_CONIC, GR_OPAC, GR_COLOR, GR_ABS = 0, 2, 5, 6, 12
 
@@ -97,6 +98,17 @@ _BACKWARD_OPTIMIZER = None
 def set_backward_optimizer(obj) -> None:
     global _BACKWARD_OPTIMIZER
     _BACKWARD_OPTIMIZER = obj
+
+
+# Exchange of view-space gradient rows between view-parallel ranks
+# (distributed.GatherRowsSync): when set, the projection backward hands its rows to
+# `exchange(rows, radii)` and runs over the cameras of ALL ranks it gets back.
+_ROW_EXCHANGE = None
+
+
+def set_row_exchange(obj) -> None:
+    global _ROW_EXCHANGE
+    _ROW_EXCHANGE = obj
 
 
 def set_grad_arena(arena: Optional[GradArena]) -> None:
@@ -220,14 +232,30 @@ class _ProjectSH(torch.autograd.Function):
         if (bo is not None and ctx.split and sh_degree >= 0 and sh_b is not None
                 and sh_b.shape[1] == 15 and activations == (ACT_EXP_SCALES | ACT_SIGMOID_OPAC)
                 and all(ctx.needs_input_grad[:6])):
+            ex = _ROW_EXCHANGE
+            if ex is not None and (C != 1 or v_depths is not None or v_comps is not None
+                                   or depth_channel >= 0):
+                raise NotImplementedError("row exchange: one colour-only view per rank per step")
             args = bo.claim((means, quats, scales, ctx.raw_opacities, sh_a, sh_b))
             if args is not None:
                 P, M, V, ss, bc2, beta1, beta2, eps = args
+                if ex is not None:
+                    # every rank's 40-byte rows, and every rank's camera: the sum over the
+                    # views is taken inside the kernel, identically on all ranks
+                    rows_all, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
+                    call("gsr_project_bwd_adam", W, N, ptr(vm_all), ptr(Ks_all), ptr(campos_all),
+                         width, height, eps2d, sh_degree, None, ptr(rows_all), PACKED_ROW, None,
+                         None, -1, activations, ptr(opac_act), P, M, V, ss, bc2, beta1, beta2,
+                         eps, _stream())
+                    return (None,) * 10
                 call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
-                     height, eps2d, sh_degree, ptr(radii), ptr(rows), ptr(v_depths), ptr(v_comps),
-                     depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2, beta1, beta2,
-                     eps, _stream())
+                     height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
+                     ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
+                     beta1, beta2, eps, _stream())
                 return (None,) * 10
+        if _ROW_EXCHANGE is not None:
+            raise RuntimeError("row exchange is set but the fused backward optimizer did not apply "
+                               "(needs FusedAdam.fuse_into_backward on the six raw parameters)")
         if activations & ACT_SIGMOID_OPAC:
             v_opacities = _grad_out("opacities", opac_act)
         v_means = _grad_out("means", means)

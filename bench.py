@@ -123,6 +123,10 @@ def main():
     ap.add_argument("--gaussians", type=int, default=N_GAUSS)
     ap.add_argument("--ssim-lambda", type=float, default=0.0,
                     help="0 (default): the metric's L1 loss; 0.2: the reference's full loss (runner.py:506-510)")
+    ap.add_argument("--sync", choices=("gather", "allreduce"), default="gather",
+                    help="N>1: all-gather of the 40-byte view-space gradient rows + projection "
+                         "backward over all ranks' cameras (default), or all-reduce of the 59N "
+                         "parameter gradients")
     ap.add_argument("--separate-adam", action="store_true",
                     help="N=1: keep gsr_project_bwd and gsr_adam_step as two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +185,7 @@ def main():
     vms, Ks = scenes.cameras(range(N_CAMS), width=WIDTH, height=HEIGHT)
     c2ws = torch.linalg.inv(vms).contiguous().to(dev)   # (linalg.inv returns column-major batches)
     Ks = Ks.to(dev)
+    c2ws_w, Ks_w = torch.cat([c2ws, c2ws[:world]]), torch.cat([Ks, Ks[:world]])
     gen = torch.Generator().manual_seed(2)
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
     cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
@@ -188,13 +193,23 @@ def main():
         # one process, photometric loss only: the projection backward applies the Adam update
         # itself (gsr_project_bwd_adam); with an all-reduce in between the two stay separate
         optimizers.fuse_into_backward(True)
-    sync = distributed.GradSync(splats, world, force=use_dist) if use_dist else None
-    if sync is not None and not args.no_optimizer:
-        sync.attach(optimizers)      # Adam on chunk k overlaps the all-reduce of chunk k+1
+    sync = None
+    gather = use_dist and args.sync == "gather" and not args.no_optimizer
+    if gather:
+        # the same sum of per-view gradients, exchanged as 40-byte view-space rows (one
+        # all-gather) instead of 236-byte parameter gradients (one all-reduce); DESIGN.md 6
+        sync = distributed.GatherRowsSync(optimizers, world, rank)
+    elif use_dist:
+        sync = distributed.GradSync(splats, world, force=use_dist)
+        if not args.no_optimizer:
+            sync.attach(optimizers)      # Adam on chunk k overlaps the all-reduce of chunk k+1
     info_box = {}
 
     def step(k: int):
         cam = (k * world + rank) % N_CAMS
+        if gather:           # cameras of all ranks in this step: a contiguous slice (no index kernels,
+            a = (k * world) % N_CAMS      # no host-to-device copy) of the wrapped camera table
+            sync.set_views(c2ws_w[a:a + world], Ks_w[a:a + world])
         _, info = runner.train_step(
             splats, None if args.no_optimizer else optimizers, c2ws[cam:cam + 1], Ks[cam:cam + 1],
             targets[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync, ssim_lambda=args.ssim_lambda)
@@ -280,7 +295,8 @@ def main():
                              + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
                              + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
-                             + (", RCCL all-reduce of 59N fp32 grads" if world > 1 else "")),
+                             + ((", RCCL all-gather of 10N fp32 view-space gradient rows" if gather
+                                 else ", RCCL all-reduce of 59N fp32 grads") if world > 1 else "")),
                 "gaussians": N, "visible": V, "n_isects": I, "pixels": P,
                 "parallelism": f"view-parallel x{world}" if world > 1 else "single",
             },

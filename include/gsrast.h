@@ -49,6 +49,8 @@ extern "C" {
 #define GSR_GR_OPAC 5     /* 1: dL/d opacity                 */
 #define GSR_GR_COLOR 6    /* CH (<=5): dL/d colour channels  */
 #define GSR_GR_ABS 12     /* 2: sum |dL/d means2d| (absgrad) */
+#define GSR_PACKED_ROW 10 /* floats of a packed row (gsr_pack_grad_rows): slots 0..8 as above + */
+#define GSR_PACKED_VIS 9  /*   slot 9 = 1.0 if the pair is visible (both radii > 0), else 0     */
 /* `activations` bits of gsr_project_fwd/bwd: the reference's A1 step
  * (gs_init_compare/runner.py:324-325) fused into the kernels. */
 #define GSR_ACT_EXP_SCALES 1   /* `scales` holds log-scales: scale = exp(raw)          */
@@ -104,6 +106,15 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
                                           (times o(1-o) with GSR_ACT_SIGMOID_OPAC) */,
                     void *stream);
 
+/* Multi-GPU exchange of VIEW-SPACE gradients: instead of all-reducing
+ * the 59 floats per Gaussian of parameter gradients, every rank packs the 9 floats per Gaussian
+ * its compositing backward produced (+ a visibility flag: 40 bytes), the ranks all-gather the
+ * packed rows, and each rank runs gsr_project_bwd_adam over ALL ranks' cameras (C = world size):
+ * the same sum of per-view gradients, 6x fewer bytes on the wire, and the Adam update stays
+ * fused in the backward. packed [n,GSR_PACKED_ROW]; rows of invisible pairs are zeroed. */
+int gsr_pack_grad_rows(int64_t n, const float *grad_rows /* [n,16] */, const int32_t *radii,
+                       float *packed, void *stream);
+
 /* Optimizer in backward (A8 fused into the backward of A1+A3+A4): gsr_project_bwd and
  * gsr_adam_step in ONE pass over the parameters, for the single-process case where nothing
  * (no all-reduce, no other loss term) has to see the parameter gradients. params /
@@ -113,8 +124,11 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
  * read as the inputs of the backward and updated in place; no gradient is written.
  * Requires activations == GSR_ACT_EXP_SCALES | GSR_ACT_SIGMOID_OPAC. */
 int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks, const float *campos,
-                         int width, int height, float eps2d, int sh_degree, const int32_t *radii,
-                         const float *grad_rows, const float *v_depths,
+                         int width, int height, float eps2d, int sh_degree,
+                         const int32_t *radii /* NULL with packed rows: visibility from the row */,
+                         const float *grad_rows,
+                         int grad_stride /* GSR_GRAD_ROW, or GSR_PACKED_ROW for gathered rows */,
+                         const float *v_depths,
                          const float *v_compensations, int depth_channel, int activations,
                          const float *opacities_act, void *const *params, void *const *exp_avg,
                          void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,

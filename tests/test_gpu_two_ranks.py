@@ -39,6 +39,33 @@ def _setup():
     return runner, D, splats, D.fuse_optimizers(splats, opts), c2w, K, target
 
 
+def _worker_gather(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        runner, D, splats, fused, c2w, K, target = _setup()
+        sync = D.GatherRowsSync(fused, world, rank)
+        try:
+            for step in range(3):
+                cams = [D.shard_views(6, step, r, world) for r in range(world)]
+                sync.set_views(c2w[cams], K[cams])
+                cam = cams[rank]
+                runner.train_step(splats, fused, c2w[cam:cam + 1], K[cam:cam + 1], target[cam:cam + 1],
+                                  step=5000 + step, grad_sync=sync)
+                assert all(p.grad is None for p in splats.values())
+        finally:
+            sync.close()
+        torch.cuda.synchronize()
+        q.put((rank, {k: p.detach().cpu().numpy() for k, p in splats.items()}, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -61,6 +88,53 @@ def _worker(rank, world, port, q):
         q.put((rank, None, traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def _two_camera_batch_reference():
+    """One process, both cameras of each step in one batch (loss = sum of per-view means)."""
+    runner, D, splats, fused, c2w, K, target = _setup()
+    for step in range(3):
+        cams = [D.shard_views(6, step, r, 2) for r in range(2)]
+        for p in splats.values():
+            p.grad = None
+        total = 0
+        for cam in cams:
+            renders, alphas, info = runner.rasterize_splats(
+                splats, c2w[cam:cam + 1], K[cam:cam + 1], W, H, sh_degree=3)
+            total = total + (renders - target[cam:cam + 1]).abs().mean()
+        total.backward()
+        fused.step()
+        fused.zero_grad(set_to_none=True)
+    return {k: p.detach().cpu() for k, p in splats.items()}
+
+
+def _run_two(worker):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        rank, params, msg = q.get(timeout=300)
+        assert msg == "ok", msg
+        res[rank] = {k: torch.from_numpy(v) for k, v in params.items()}
+    for p in procs:
+        p.join(60)
+    return res
+
+
+def test_two_ranks_gathered_view_space_rows_match_two_camera_batch():
+    """GatherRowsSync: each rank packs its 40-byte view-space gradient rows, one all-gather,
+    every rank runs the projection backward + Adam over BOTH cameras. Replicas bit-identical,
+    and equal to one process stepping on the two-camera batch."""
+    res = _run_two(_worker_gather)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), f"replicas diverged in {k}"
+    ref = _two_camera_batch_reference()
+    for k in ref:
+        assert torch.allclose(res[0][k], ref[k], rtol=1e-4, atol=1e-6), f"{k}: gathered rows != two-camera batch"
 
 
 def test_two_ranks_one_gpu_pipelined_allreduce_matches_two_camera_batch():
