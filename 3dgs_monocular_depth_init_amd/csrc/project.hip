@@ -174,8 +174,15 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     int64_t g = (int64_t)c * N + i;
     const float *row = grad_rows + g * row_stride;
     // visibility: the radii of the pair, or (rows gathered from other ranks, packed by
-    // gsr_pack_grad_rows) the flag in slot GSR_PACKED_VIS of the row
-    if (radii ? (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) : (row[GSR_PACKED_VIS] == 0.f)) continue;
+    // gsr_pack_grad_rows, which zeroes the rows of invisible pairs) "the row is not all zero"
+    if (radii) {
+      if (radii[g * 2] <= 0 || radii[g * 2 + 1] <= 0) continue;
+    } else {
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < GSR_PACKED_ROW; ++k) any |= (row[k] != 0.f);
+      if (!any) continue;
+    }
     v_op += row[GSR_GR_OPAC];
     float v_m2d[2] = {row[GSR_GR_MEAN2D], row[GSR_GR_MEAN2D + 1]};
     float v_con[3] = {row[GSR_GR_CONIC], row[GSR_GR_CONIC + 1], row[GSR_GR_CONIC + 2]};
@@ -430,7 +437,7 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
 }
 
 // Compact form of the gradient rows for the exchange between view-parallel ranks: the 9 used
-// floats of a 64-byte row + a visibility flag = 40 bytes per Gaussian (see gsr_pack_grad_rows).
+// floats of a 64-byte row = 36 bytes per Gaussian, zero for invisible pairs (gsr_pack_grad_rows).
 namespace gsr {
 __global__ void __launch_bounds__(256)
 pack_grad_rows_kernel(int64_t n, const float *__restrict__ rows, const int32_t *__restrict__ radii,
@@ -445,7 +452,6 @@ pack_grad_rows_kernel(int64_t n, const float *__restrict__ rows, const int32_t *
   o[0] = vis ? a.x : 0.f; o[1] = vis ? a.y : 0.f; o[2] = vis ? a.z : 0.f; o[3] = vis ? a.w : 0.f;
   o[4] = vis ? b.x : 0.f; o[5] = vis ? b.y : 0.f; o[6] = vis ? b.z : 0.f; o[7] = vis ? b.w : 0.f;
   o[8] = vis ? c : 0.f;
-  o[GSR_PACKED_VIS] = vis ? 1.f : 0.f;
 }
 }  // namespace gsr
 
@@ -479,7 +485,7 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
                   step_size && bc2_sqrt,
               "project_bwd_adam: null pointer");
   GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW,
-              "project_bwd_adam: grad_stride %d (16 = scratch rows, 10 = packed rows)", grad_stride);
+              "project_bwd_adam: grad_stride %d (16 = scratch rows, 9 = packed rows)", grad_stride);
   GSR_REQUIRE(radii || grad_stride == GSR_PACKED_ROW,
               "project_bwd_adam: radii may be NULL only with packed rows (visibility flag in the row)");
   GSR_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_bwd_adam: sh_degree %d", sh_degree);

@@ -136,9 +136,9 @@ class GatherRowsSync:
 
     The parameter gradients are 59 floats per Gaussian, but what a view contributes is
     determined by the 9 floats per Gaussian its compositing backward leaves in the 64-byte
-    rows (d loss / d means2d, conic, opacity, colour). So: every rank packs its rows to 40
-    bytes (9 floats + a visibility flag, `gsr_pack_grad_rows`), ONE all-gather moves them
-    (40 MB per rank at 1 M Gaussians instead of a 236 MB all-reduce), and every rank runs the
+    rows (d loss / d means2d, conic, opacity, colour). So: every rank packs its rows to 36
+    bytes (the 9 floats, zero for invisible pairs, `gsr_pack_grad_rows`), ONE all-gather moves them
+    (36 MB per rank at 1 M Gaussians instead of a 236 MB all-reduce), and every rank runs the
     projection backward over the cameras of ALL ranks (`C = world_size`, the batch path of
     `gsr_project_bwd_adam`), which also keeps the Adam update fused in the backward. Every
     rank sums the views in rank order, so the replicas stay bit-identical.
@@ -165,14 +165,14 @@ class GatherRowsSync:
 
     def exchange(self, rows, radii, N: int):
         """Called by the projection backward: local rows [N,16] + radii -> all ranks' packed
-        rows [W*N,10] and all ranks' cameras."""
+        rows [W*N,9] and all ranks' cameras."""
         from ._lib import call, ptr
         if self._views is None:
             raise RuntimeError("GatherRowsSync.set_views() must be called before every step")
         dev = rows.device
         W = self.world
         if self._buf is None or self._buf.shape[0] != W * N:
-            self._buf = torch.empty(W * N, 10, dtype=torch.float32, device=dev)
+            self._buf = torch.empty(W * N, 9, dtype=torch.float32, device=dev)
         mine = self._buf[self.rank * N:(self.rank + 1) * N]
         call("gsr_pack_grad_rows", N, ptr(rows), ptr(radii), ptr(mine),
              torch.cuda.current_stream().cuda_stream)

@@ -27,7 +27,7 @@ from ._lib import call, ptr
 
 TILE = 16
 GRAD_ROW = 16
-PACKED_ROW = 10                                # GSR_PACKED_ROW
+PACKED_ROW = 9                                 # GSR_PACKED_ROW
 ACT_EXP_SCALES, ACT_SIGMOID_OPAC = 1, 2      # GSR_ACT_* of include/gsrast.h
 GR_MEAN2D, GR_CONIC, GR_OPAC, GR_COLOR, GR_ABS = 0, 2, 5, 6, 12
 
@@ -240,7 +240,7 @@ class _ProjectSH(torch.autograd.Function):
             if args is not None:
                 P, M, V, ss, bc2, beta1, beta2, eps = args
                 if ex is not None:
-                    # every rank's 40-byte rows, and every rank's camera: the sum over the
+                    # every rank's 36-byte rows, and every rank's camera: the sum over the
                     # views is taken inside the kernel, identically on all ranks
                     rows_all, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
                     call("gsr_project_bwd_adam", W, N, ptr(vm_all), ptr(Ks_all), ptr(campos_all),

@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--ssim-lambda", type=float, default=0.0,
                     help="0 (default): the metric's L1 loss; 0.2: the reference's full loss (runner.py:506-510)")
     ap.add_argument("--sync", choices=("gather", "allreduce"), default="gather",
-                    help="N>1: all-gather of the 40-byte view-space gradient rows + projection "
+                    help="N>1: all-gather of the 36-byte view-space gradient rows + projection "
                          "backward over all ranks' cameras (default), or all-reduce of the 59N "
                          "parameter gradients")
     ap.add_argument("--separate-adam", action="store_true",
@@ -196,7 +196,7 @@ def main():
     sync = None
     gather = use_dist and args.sync == "gather" and not args.no_optimizer
     if gather:
-        # the same sum of per-view gradients, exchanged as 40-byte view-space rows (one
+        # the same sum of per-view gradients, exchanged as 36-byte view-space rows (one
         # all-gather) instead of 236-byte parameter gradients (one all-reduce); DESIGN.md 6
         sync = distributed.GatherRowsSync(optimizers, world, rank)
     elif use_dist:
@@ -284,7 +284,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "train iters/sec (fwd+bwd rasterize) @1M Gaussians, 1080p",
+            "metric": "train iters/sec (fwd+bwd rasterize) @1M Gaussians, 1080p; 1/2/4/8 GPU",
             "value": args.steps * world / dt, "unit": "iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -295,7 +295,7 @@ def main():
                              + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
                              + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
-                             + ((", RCCL all-gather of 10N fp32 view-space gradient rows" if gather
+                             + ((", RCCL all-gather of 9N fp32 view-space gradient rows (equivalent to the gradient all-reduce)" if gather
                                  else ", RCCL all-reduce of 59N fp32 grads") if world > 1 else "")),
                 "gaussians": N, "visible": V, "n_isects": I, "pixels": P,
                 "parallelism": f"view-parallel x{world}" if world > 1 else "single",

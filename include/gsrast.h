@@ -49,8 +49,8 @@ extern "C" {
 #define GSR_GR_OPAC 5     /* 1: dL/d opacity                 */
 #define GSR_GR_COLOR 6    /* CH (<=5): dL/d colour channels  */
 #define GSR_GR_ABS 12     /* 2: sum |dL/d means2d| (absgrad) */
-#define GSR_PACKED_ROW 10 /* floats of a packed row (gsr_pack_grad_rows): slots 0..8 as above + */
-#define GSR_PACKED_VIS 9  /*   slot 9 = 1.0 if the pair is visible (both radii > 0), else 0     */
+#define GSR_PACKED_ROW 9  /* floats of a packed row (gsr_pack_grad_rows): slots 0..8 as above;  */
+                          /*   an all-zero row = invisible pair (or one that contributes nothing) */
 /* `activations` bits of gsr_project_fwd/bwd: the reference's A1 step
  * (gs_init_compare/runner.py:324-325) fused into the kernels. */
 #define GSR_ACT_EXP_SCALES 1   /* `scales` holds log-scales: scale = exp(raw)          */
@@ -108,10 +108,11 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
 
 /* Multi-GPU exchange of VIEW-SPACE gradients: instead of all-reducing
  * the 59 floats per Gaussian of parameter gradients, every rank packs the 9 floats per Gaussian
- * its compositing backward produced (+ a visibility flag: 40 bytes), the ranks all-gather the
+ * its compositing backward produced (36 bytes; rows of invisible pairs are zero), the ranks all-gather the
  * packed rows, and each rank runs gsr_project_bwd_adam over ALL ranks' cameras (C = world size):
  * the same sum of per-view gradients, 6x fewer bytes on the wire, and the Adam update stays
- * fused in the backward. packed [n,GSR_PACKED_ROW]; rows of invisible pairs are zeroed. */
+ * fused in the backward. packed [n,GSR_PACKED_ROW]; rows of invisible pairs are zeroed, and the
+ * backward skips all-zero rows. */
 int gsr_pack_grad_rows(int64_t n, const float *grad_rows /* [n,16] */, const int32_t *radii,
                        float *packed, void *stream);
 

@@ -126,7 +126,7 @@ def _run_two(worker):
 
 
 def test_two_ranks_gathered_view_space_rows_match_two_camera_batch():
-    """GatherRowsSync: each rank packs its 40-byte view-space gradient rows, one all-gather,
+    """GatherRowsSync: each rank packs its 36-byte view-space gradient rows, one all-gather,
     every rank runs the projection backward + Adam over BOTH cameras. Replicas bit-identical,
     and equal to one process stepping on the two-camera batch."""
     res = _run_two(_worker_gather)
