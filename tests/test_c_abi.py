@@ -59,3 +59,29 @@ def test_product_has_no_oracle_or_cpu_fallback():
 
 def pkg_err():
     return importlib.import_module("3dgs_monocular_depth_init_amd._lib").GsrastError
+
+
+def test_gsplat_shim_exports_what_the_reference_imports():
+    """runner.py:19-21 / trainer.py:10-11 / config.py:5: rasterization, the two strategies,
+    the launcher. (Importing needs no GPU; calling the launcher without one must say so.)"""
+    import sys
+    from pathlib import Path
+    shims = str(Path(__file__).resolve().parents[1] / "shims")
+    sys.path.insert(0, shims)
+    try:
+        for name in [n for n in sys.modules if n == "gsplat" or n.startswith("gsplat.")]:
+            del sys.modules[name]
+        from gsplat.distributed import cli
+        from gsplat.rendering import rasterization
+        from gsplat.strategy import DefaultStrategy, MCMCStrategy
+        assert callable(rasterization) and callable(cli)
+        assert DefaultStrategy().refine_every == 100 and MCMCStrategy().cap_max == 1_000_000
+        import torch
+        if not torch.cuda.is_available():
+            import pytest
+            with pytest.raises(RuntimeError, match="ROCm"):
+                cli(lambda *a: None, None)
+    finally:
+        sys.path.remove(shims)
+        for name in [n for n in sys.modules if n == "gsplat" or n.startswith("gsplat.")]:
+            del sys.modules[name]
