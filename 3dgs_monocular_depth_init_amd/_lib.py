@@ -42,7 +42,7 @@ SIGNATURES = {
 SIGNATURES["gsr_ssim_workspace_doubles"] = [_i, _i, _i, _i]
 SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p]
 SIGNATURES["gsr_ssim_l1_bwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p]
-SIGNATURES["gsr_l1_fwd"] = [_i64, _p, _p, _p, _p, _p]
+SIGNATURES["gsr_l1_fwd"] = [_i64, _p, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_l1_bwd"] = [_i64, _p, _p, _p, _f, _p, _p]
 SIGNATURES["gsr_debug_tree_reduce8"] = [_p, _p, _p, _p]
 SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p, _p]

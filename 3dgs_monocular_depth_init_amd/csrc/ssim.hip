@@ -237,7 +237,8 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
 // Plain L1 (runner.py:506 with ssim_lambda = 0): contiguous buffers, 16 B per lane.
 __global__ void __launch_bounds__(256)
 l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
-              double *__restrict__ ws, float *__restrict__ mean_out) {
+              double *__restrict__ ws, float *__restrict__ mean_out,
+              float *__restrict__ unit_grad, float scale) {
   // fp32 partial per thread (a few dozen terms of magnitude <= 1), fp64 across threads.
   // Few, fat workgroups: the kernel ends with one same-address fp64 atomic per workgroup
   // and those serialise at the memory side (2048 of them cost more than the 50 MB read),
@@ -248,18 +249,29 @@ l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ 
   const int64_t n4 = n >> 2;
   const float4 *a4 = reinterpret_cast<const float4 *>(a);
   const float4 *b4 = reinterpret_cast<const float4 *>(b);
-  auto l1 = [](const float4 &x, const float4 &y) {
-    return (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+  // unit_grad (optional): d mean|a-b| / d a = sign(a-b)/n, written while the operands are in
+  // registers anyway -- under the usual root gradient of 1 the backward then needs no launch
+  float4 *g4 = reinterpret_cast<float4 *>(unit_grad);
+  auto sg = [scale](float d) { return d > 0.f ? scale : (d < 0.f ? -scale : 0.f); };
+  auto l1 = [&](int64_t idx, const float4 &x, const float4 &y) {
+    const float dx = x.x - y.x, dy = x.y - y.y, dz = x.z - y.z, dw = x.w - y.w;
+    if (unit_grad) g4[idx] = make_float4(sg(dx), sg(dy), sg(dz), sg(dw));
+    return (fabsf(dx) + fabsf(dy)) + (fabsf(dz) + fabsf(dw));
   };
   int64_t i = tid;
   for (; i + 3 * nthreads < n4; i += 4 * nthreads) {
     const float4 x0 = a4[i], x1 = a4[i + nthreads], x2 = a4[i + 2 * nthreads], x3 = a4[i + 3 * nthreads];
     const float4 y0 = b4[i], y1 = b4[i + nthreads], y2 = b4[i + 2 * nthreads], y3 = b4[i + 3 * nthreads];
-    part += (l1(x0, y0) + l1(x1, y1)) + (l1(x2, y2) + l1(x3, y3));
+    part += (l1(i, x0, y0) + l1(i + nthreads, x1, y1)) +
+            (l1(i + 2 * nthreads, x2, y2) + l1(i + 3 * nthreads, x3, y3));
   }
-  for (; i < n4; i += nthreads) part += l1(a4[i], b4[i]);
+  for (; i < n4; i += nthreads) part += l1(i, a4[i], b4[i]);
   if (tid == 0)
-    for (int64_t k = n4 << 2; k < n; ++k) part += fabsf(a[k] - b[k]);
+    for (int64_t k = n4 << 2; k < n; ++k) {
+      const float d = a[k] - b[k];
+      if (unit_grad) unit_grad[k] = sg(d);
+      part += fabsf(d);
+    }
   __shared__ double red[4];
   double acc = wave_sum_f64((double)part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -302,12 +314,13 @@ l1_bwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ 
 }  // namespace gsr
 
 extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *workspace,
-                          float *mean_out, void *stream) {
+                          float *mean_out, float *unit_grad, void *stream) {
   GSR_REQUIRE(n > 0 && a && b && workspace && mean_out, "l1_fwd: bad arguments");
-  GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "l1_fwd: buffers must be 16-byte aligned");
+  GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)unit_grad) % 16 == 0,
+              "l1_fwd: buffers must be 16-byte aligned");
   int blocks = (int)(gsr::ceil_div64(n, 4096) < 512 ? gsr::ceil_div64(n, 4096) : 512);
   hipLaunchKernelGGL(gsr::l1_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
-                     workspace, mean_out);
+                     workspace, mean_out, unit_grad, (float)(1.0 / (double)n));
   GSR_CHECK_LAUNCH("l1_fwd");
   return GSR_OK;
 }

@@ -133,9 +133,6 @@ def rasterize_splats(
     return render_colors, render_alphas, info
 
 
-_ONES: Dict = {}     # device -> cached scalar 1.0, the root gradient of loss.backward()
-
-
 def train_step(
     splats,
     optimizers: Optional[Dict[str, torch.optim.Optimizer]],
@@ -173,9 +170,8 @@ def train_step(
         loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
     if scale_reg > 0.0:                                                  # runner.py:540-545
         loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
-    one = _ONES.get(loss.device)
-    if one is None:
-        one = _ONES[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    from .losses import unit_gradient
+    one = unit_gradient(loss.device)
     loss.backward(one if one.dtype == loss.dtype else None)              # runner.py:547 (root
     # gradient handed over instead of a ones_like + fill launch per step)
     if grad_sync is not None:
