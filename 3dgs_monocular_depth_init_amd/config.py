@@ -2,10 +2,22 @@
 /root/reference/gs_init_compare/config.py:20-66 (MonocularDepthInitConfig) and
 the rasterisation-related fields of Config (config.py:103-149)."""
 from dataclasses import dataclass, field
+from enum import Enum
 from typing import Literal, Optional, Union
 
 from .depth_alignment.config import DepthAlignmentConfig
 from .depth_subsampling.config import AdaptiveSubsamplingConfig, NumSfMPointsMaskConfig
+
+
+class Metric3dBackbone(str, Enum):          # depth_prediction/configs.py:33-36
+    vits = "vits"
+    vitl = "vitl"
+    vitg = "vitg"
+
+
+@dataclass
+class Metric3dV2Config:                     # depth_prediction/configs.py:39-46
+    backbone: Metric3dBackbone = Metric3dBackbone.vitl
 
 
 @dataclass
@@ -21,6 +33,9 @@ class MonocularDepthInitConfig:
     limit_init_scale: bool = False
     init_scale_clamp_quantile: float = 0.75
     noise_std_scene_frac: Optional[float] = None
+    metric3d: Metric3dV2Config = field(default_factory=Metric3dV2Config)
+    ignore_cache: bool = False
+    cache_dir: Optional[str] = "__mono_depth_cache__"     # None (an extra): no depth cache
 
 
 @dataclass

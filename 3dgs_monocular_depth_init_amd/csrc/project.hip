@@ -398,6 +398,47 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
   return GSR_OK;
 }
 
+namespace gsr {
+static int project_bwd_launch(int C, int N, const float *means, const float *quats,
+                              const float *scales, const float *viewmats, const float *Ks,
+                              const float *campos, int width, int height, float eps2d,
+                              int sh_degree, const float *sh0, int sh0_stride, const float *shN,
+                              int shN_stride, const int32_t *radii, const float *grad_rows,
+                              int grad_stride, const float *v_depths, const float *v_compensations,
+                              int depth_channel, float *v_means, float *v_quats, float *v_scales,
+                              float *v_sh0, int v_sh0_stride, float *v_shN, int v_shN_stride,
+                              int sh_K, int activations, const float *opacities_act,
+                              float *v_opacities, void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd: bad sizes");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(means && quats && scales && viewmats && Ks && grad_rows && v_means && v_quats &&
+                  v_scales,
+              "project_bwd: null pointer");
+  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW,
+              "project_bwd: grad_stride %d (16 = scratch rows, 9 = packed rows)", grad_stride);
+  GSR_REQUIRE(radii || grad_stride == GSR_PACKED_ROW,
+              "project_bwd: radii may be NULL only with packed rows (visibility from the row)");
+  GSR_REQUIRE(sh_degree <= 3 && sh_K <= 16, "project_bwd: sh_degree/sh_K out of range");
+  if (sh_degree >= 0)
+    GSR_REQUIRE(sh0 && campos && v_sh0 && (sh_K == 1 || (shN && v_shN)) &&
+                    (sh_degree + 1) * (sh_degree + 1) <= sh_K,
+                "project_bwd: SH arguments inconsistent");
+  GSR_REQUIRE(depth_channel < 5, "project_bwd: depth_channel out of range");
+  GSR_REQUIRE(!(activations & GSR_ACT_SIGMOID_OPAC) || !v_opacities || opacities_act,
+              "project_bwd: sigmoid chain rule needs the activated opacities");
+  dim3 grid((unsigned)gsr::ceil_div(N, 256));
+  hipLaunchKernelGGL(gsr::project_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
+                     means, quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree,
+                     sh0, sh0_stride, shN, shN_stride, radii, grad_rows, grad_stride, v_depths,
+                     v_compensations,
+                     depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
+                     v_sh0_stride, v_shN, v_shN_stride, sh_K, activations, opacities_act,
+                     v_opacities, gsr::AdamFused{});
+  GSR_CHECK_LAUNCH("project_bwd");
+  return GSR_OK;
+}
+}  // namespace gsr
+
 extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *quats,
                                const float *scales, const float *viewmats, const float *Ks,
                                const float *campos, int width, int height, float eps2d,
@@ -411,29 +452,29 @@ extern "C" int gsr_project_bwd(int C, int N, const float *means, const float *qu
                                const float *opacities_act, float *v_opacities, void *stream) {
   (void)conics;
   (void)compensations;
-  GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd: bad sizes");
-  if (N == 0) return GSR_OK;
-  GSR_REQUIRE(means && quats && scales && viewmats && Ks && radii && grad_rows && v_means &&
-                  v_quats && v_scales,
-              "project_bwd: null pointer");
-  GSR_REQUIRE(sh_degree <= 3 && sh_K <= 16, "project_bwd: sh_degree/sh_K out of range");
-  if (sh_degree >= 0)
-    GSR_REQUIRE(sh0 && campos && v_sh0 && (sh_K == 1 || (shN && v_shN)) &&
-                    (sh_degree + 1) * (sh_degree + 1) <= sh_K,
-                "project_bwd: SH arguments inconsistent");
-  GSR_REQUIRE(depth_channel < 5, "project_bwd: depth_channel out of range");
-  GSR_REQUIRE(!(activations & GSR_ACT_SIGMOID_OPAC) || !v_opacities || opacities_act,
-              "project_bwd: sigmoid chain rule needs the activated opacities");
-  dim3 grid((unsigned)gsr::ceil_div(N, 256));
-  hipLaunchKernelGGL(gsr::project_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
-                     means, quats, scales, viewmats, Ks, campos, width, height, eps2d, sh_degree,
-                     sh0, sh0_stride, shN, shN_stride, radii, grad_rows, GSR_GRAD_ROW, v_depths,
-                     v_compensations,
-                     depth_channel, v_means, v_quats, v_scales, sh_degree >= 0 ? v_sh0 : nullptr,
-                     v_sh0_stride, v_shN, v_shN_stride, sh_K, activations, opacities_act,
-                     v_opacities, gsr::AdamFused{});
-  GSR_CHECK_LAUNCH("project_bwd");
-  return GSR_OK;
+  GSR_REQUIRE(radii, "project_bwd: null radii");
+  return gsr::project_bwd_launch(C, N, means, quats, scales, viewmats, Ks, campos, width, height,
+                                 eps2d, sh_degree, sh0, sh0_stride, shN, shN_stride, radii,
+                                 grad_rows, GSR_GRAD_ROW, v_depths, v_compensations, depth_channel,
+                                 v_means, v_quats, v_scales, v_sh0, v_sh0_stride, v_shN,
+                                 v_shN_stride, sh_K, activations, opacities_act, v_opacities, stream);
+}
+
+extern "C" int gsr_project_bwd_rows(int C, int N, const float *means, const float *quats,
+                                    const float *scales, const float *viewmats, const float *Ks,
+                                    const float *campos, int width, int height, float eps2d,
+                                    int sh_degree, const float *sh0, int sh0_stride,
+                                    const float *shN, int shN_stride, const int32_t *radii,
+                                    const float *grad_rows, int grad_stride, float *v_means,
+                                    float *v_quats, float *v_scales, float *v_sh0,
+                                    int v_sh0_stride, float *v_shN, int v_shN_stride, int sh_K,
+                                    int activations, const float *opacities_act,
+                                    float *v_opacities, void *stream) {
+  return gsr::project_bwd_launch(C, N, means, quats, scales, viewmats, Ks, campos, width, height,
+                                 eps2d, sh_degree, sh0, sh0_stride, shN, shN_stride, radii,
+                                 grad_rows, grad_stride, nullptr, nullptr, -1, v_means, v_quats,
+                                 v_scales, v_sh0, v_sh0_stride, v_shN, v_shN_stride, sh_K,
+                                 activations, opacities_act, v_opacities, stream);
 }
 
 // Compact form of the gradient rows for the exchange between view-parallel ranks: the 9 used

@@ -12,6 +12,7 @@ a count kernel, a scan and an emit kernel (gsr_unproject_*).
 from pathlib import Path
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .._lib import call, load, ptr
@@ -102,17 +103,31 @@ def unproject_masked(aligned_depth: torch.Tensor, valid: torch.Tensor, subsample
     return pts[:n], (rgbs[:n] if rgbs is not None else None), final_mask
 
 
-def get_pts_from_depth(predicted_depth: PredictedDepth, image, sfm_points: torch.Tensor, config,
+def _sfm_points_of(parser, image_name: str, device) -> torch.Tensor:
+    """points_from_depth.py:233-237: `parser.points[parser.point_indices[image.name]]` for any
+    object with those two attributes (the reference's colmap Parser or its nerfbaselines
+    gs_Parser); a bare [M,3] tensor / array is taken as that image's points already."""
+    if hasattr(parser, "points") and hasattr(parser, "point_indices"):
+        pts = parser.points[parser.point_indices[image_name]]
+    else:
+        pts = parser
+    if not isinstance(pts, torch.Tensor):
+        pts = torch.from_numpy(np.ascontiguousarray(pts))
+    return pts.to(device).float()
+
+
+def get_pts_from_depth(predicted_depth: PredictedDepth, image, parser, config,
                        device: str, debug_export_dir: Optional[Path] = None, return_rgb: bool = False):
-    """points_from_depth.py:215-329. `sfm_points` [M,3] replaces the reference's
-    `parser.points[parser.point_indices[image.name]]` lookup (dataset parsing is
-    out of scope). Returns (pts_world [n,3] on device, mask [H*W] on CPU, P [3,4])
-    (+ rgbs [n,3] when return_rgb)."""
+    """points_from_depth.py:215-329, same positional arguments: `parser` is the dataset parser
+    (`.points` [P,3], `.point_indices[image.name]`), or -- an extra -- the image's SfM points
+    [M,3] themselves. Returns (pts_world [n,3] on device, mask [H*W] on CPU, P [3,4])
+    (+ rgbs [n,3] when return_rgb). The debug exports of the reference (matplotlib / PLY
+    files) are not produced; `debug_export_dir` is accepted and ignored."""
     imsize = predicted_depth.depth.T.shape                       # (W, H)
     R = image.cam2world[:3, :3].T
     C = image.cam2world[:3, 3]
     P = image.K @ R @ torch.hstack([torch.eye(3), -C[:, None].cpu()]).to(image.K.device)
-    sfm_points = sfm_points.to(device).float()
+    sfm_points = _sfm_points_of(parser, image.name, device)
     cam2world = image.cam2world.to(device).float()
     P = P.to(device).float()
     K = image.K.to(device).float()

@@ -10,8 +10,13 @@ interchange with the reference and its viewers.
   (zeros), f_dc_0..2, f_rest_*, opacity (logit), scale_0..2 (log), rot_0..3
   (wxyz), little-endian float32. f_rest is channel-major ([3, K-1] flattened),
   as in the original 3DGS viewer format.
-* depth cache: `torch.save(PredictedDepth)` per image under
-  cache_dir/model/dataset/name.pth (monocular_depth_init.py:60-87).
+* depth cache: one file per image at the reference's path
+  cache_dir/model/dataset/{image_name}.pth (monocular_depth_init.py:60-87). The PAYLOAD is
+  one-way only: the reference pickles the PredictedDepth object (`torch.save(depth, path)`),
+  which a `weights_only=True` load refuses; this build writes and reads a plain dict of the
+  dataclass fields instead. A reference-side reader needs `PredictedDepth(**torch.load(p))`
+  (shown in INTEGRATION.md); files written by the reference are ignored with a warning and
+  the depth is predicted again (predict_depth_or_get_cached_depth's except branch).
 """
 from __future__ import annotations
 
@@ -87,8 +92,9 @@ def load_ply(path) -> Dict[str, torch.Tensor]:
 
 
 def depth_cache_path(cache_dir, model_name: str, dataset_name: str, image_name: str) -> Path:
-    """monocular_depth_init.py:60-87."""
-    return Path(cache_dir) / model_name / dataset_name / (Path(image_name).stem + ".pth")
+    """monocular_depth_init.py:66-71: cache_dir / model.name / dataset_name / f"{image_name}.pth"
+    (the image name keeps its extension, e.g. `DSC0001.JPG.pth`)."""
+    return Path(cache_dir) / model_name / dataset_name / f"{image_name}.pth"
 
 
 def save_predicted_depth(pred, path) -> None:

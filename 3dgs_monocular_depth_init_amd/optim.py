@@ -32,6 +32,7 @@ class FusedAdam:
             raise ValueError("at most 8 tensors per fused launch")
         self.optimizers = optimizers
         self.grad_sync = None           # distributed.GradSync.attach() sets this
+        self._claimed = False           # the projection backward applied this step's update
 
     # dict-like access so existing code (`optimizers["means"]`, `.values()`) keeps working
     def __getitem__(self, k):
@@ -101,6 +102,19 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self) -> None:
+        if self._claimed:
+            # optimizer in backward: the update (and the step count) already happened inside
+            # loss.backward(). A gradient found here reached the parameters OUTSIDE the
+            # rasterizer (a regulariser, a second loss term): stepping on it would count the
+            # step twice and decay the moments twice -- refuse instead of training wrongly.
+            self._claimed = False
+            stray = [n for n, o in self.optimizers.items()
+                     if o.param_groups[0]["params"][0].grad is not None]
+            if stray:
+                raise RuntimeError(
+                    f"FusedAdam: optimizer-in-backward already stepped, but {stray} carry gradients "
+                    "from outside the rasterizer; disable fuse_into_backward for such losses")
+            return
         items, beta1, beta2, eps = self._prepare()
         sync = self.grad_sync
         pending = sync.take_pending() if sync is not None else []
@@ -140,10 +154,15 @@ class FusedAdam:
         """Single-process training with a purely photometric loss: let the projection
         backward apply this optimizer's update itself (`gsr_project_bwd_adam`) -- the
         parameter gradients are then never written to memory nor read back, and
-        `step()` finds nothing left to do. Do NOT enable together with a gradient
-        all-reduce, gradient clipping, or loss terms that reach the parameters outside
-        the rasterizer (their gradients would be applied without this step's moments),
-        nor with more than one backward per step."""
+        `step()` finds nothing left to do. Not valid together with a gradient all-reduce,
+        gradient clipping, more than one backward per step, or loss terms that reach the
+        parameters outside the rasterizer: `step()` raises when it finds such a gradient,
+        and `runner.train_step` raises for the reference's opacity / scale regularisers.
+        ORDER: the update lands during `loss.backward()`, i.e. before
+        `strategy.step_post_backward`, whereas the reference runs the strategy first
+        (runner.py:638-679). `runner.train_step` therefore suspends the fusion on every step
+        on which the strategy edits parameters or optimizer state (`strategy.mutates_params`),
+        so those steps run in the reference's order."""
         from .rendering import set_backward_optimizer
         set_backward_optimizer(self if enable else None)
 
@@ -181,6 +200,7 @@ class FusedAdam:
             ps.append(p.data_ptr()); ms.append(st["exp_avg"].data_ptr()); vs.append(st["exp_avg_sq"].data_ptr())
             ss.append(float(grp["lr"]) / (1.0 - beta1 ** t))
             bc2.append((1.0 - beta2 ** t) ** 0.5)
+        self._claimed = True
         PA = C.c_void_p * 6
         FA = C.c_float * 6
         return PA(*ps), PA(*ms), PA(*vs), FA(*ss), FA(*bc2), beta1, beta2, eps

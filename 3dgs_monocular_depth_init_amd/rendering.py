@@ -228,21 +228,25 @@ class _ProjectSH(torch.autograd.Function):
             v_comps = _f32c(v_comps)
         else:
             v_comps = None
+        ex = _ROW_EXCHANGE
+        fusable = (ctx.split and sh_degree >= 0 and sh_b is not None and sh_b.shape[1] == 15
+                   and activations == (ACT_EXP_SCALES | ACT_SIGMOID_OPAC)
+                   and all(ctx.needs_input_grad[:6]))
+        rows_all = None
+        if ex is not None:
+            if (not fusable or C != 1 or v_depths is not None or v_comps is not None
+                    or depth_channel >= 0):
+                raise NotImplementedError(
+                    "row exchange: one colour-only view per rank per step, on the six raw parameters")
+            # every rank's 36-byte rows, and every rank's camera: the sum over the views is
+            # taken inside the projection backward, identically on all ranks
+            rows_all, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
         bo = _BACKWARD_OPTIMIZER
-        if (bo is not None and ctx.split and sh_degree >= 0 and sh_b is not None
-                and sh_b.shape[1] == 15 and activations == (ACT_EXP_SCALES | ACT_SIGMOID_OPAC)
-                and all(ctx.needs_input_grad[:6])):
-            ex = _ROW_EXCHANGE
-            if ex is not None and (C != 1 or v_depths is not None or v_comps is not None
-                                   or depth_channel >= 0):
-                raise NotImplementedError("row exchange: one colour-only view per rank per step")
+        if bo is not None and fusable:
             args = bo.claim((means, quats, scales, ctx.raw_opacities, sh_a, sh_b))
             if args is not None:
                 P, M, V, ss, bc2, beta1, beta2, eps = args
-                if ex is not None:
-                    # every rank's 36-byte rows, and every rank's camera: the sum over the
-                    # views is taken inside the kernel, identically on all ranks
-                    rows_all, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
+                if rows_all is not None:
                     call("gsr_project_bwd_adam", W, N, ptr(vm_all), ptr(Ks_all), ptr(campos_all),
                          width, height, eps2d, sh_degree, None, ptr(rows_all), PACKED_ROW, None,
                          None, -1, activations, ptr(opac_act), P, M, V, ss, bc2, beta1, beta2,
@@ -253,9 +257,20 @@ class _ProjectSH(torch.autograd.Function):
                      ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
                      beta1, beta2, eps, _stream())
                 return (None,) * 10
-        if _ROW_EXCHANGE is not None:
-            raise RuntimeError("row exchange is set but the fused backward optimizer did not apply "
-                               "(needs FusedAdam.fuse_into_backward on the six raw parameters)")
+        if rows_all is not None:
+            # gathered rows, optimizer NOT fused (a step on which the strategy must see the
+            # gradients before the update): the W-view gradients are written out, identical on
+            # every rank, and the optimizer steps afterwards as in the reference's order
+            v_opacities = _grad_out("opacities", opac_act)
+            v_means, v_quats, v_scales = (_grad_out("means", means), _grad_out("quats", quats),
+                                          _grad_out("scales", scales))
+            v_sh_a, v_sh_b = _grad_out("sh0", sh_a), _grad_out("shN", sh_b)
+            call("gsr_project_bwd_rows", W, N, ptr(means), ptr(quats), ptr(scales), ptr(vm_all),
+                 ptr(Ks_all), ptr(campos_all), width, height, eps2d, sh_degree, ptr(sh_a), 3,
+                 ptr(sh_b), 45, None, ptr(rows_all), PACKED_ROW, ptr(v_means), ptr(v_quats),
+                 ptr(v_scales), ptr(v_sh_a), 3, ptr(v_sh_b), 45, 16, activations, ptr(opac_act),
+                 ptr(v_opacities), _stream())
+            return v_means, v_quats, v_scales, v_opacities, v_sh_a, v_sh_b, None, None, None, None
         if activations & ACT_SIGMOID_OPAC:
             v_opacities = _grad_out("opacities", opac_act)
         v_means = _grad_out("means", means)
@@ -580,7 +595,8 @@ def rasterization(
     if distributed:
         raise NotImplementedError(
             "distributed=True (gsplat's Gaussian-sharded all-to-all) is not built; use the "
-            "view-parallel replicas of `distributed.ViewParallel` and call with distributed=False"
+            "view-parallel replicas (`distributed.GradSync` / `distributed.GatherRowsSync`) and "
+            "call with distributed=False"
         )
     if sparse_grad:
         raise NotImplementedError("sparse_grad=True needs packed indices; not built")

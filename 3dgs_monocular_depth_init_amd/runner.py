@@ -170,10 +170,26 @@ def train_step(
         loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
     if scale_reg > 0.0:                                                  # runner.py:540-545
         loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
+    from . import rendering as _R
     from .losses import unit_gradient
-    one = unit_gradient(loss.device)
-    loss.backward(one if one.dtype == loss.dtype else None)              # runner.py:547 (root
-    # gradient handed over instead of a ones_like + fill launch per step)
+    fused = _R._BACKWARD_OPTIMIZER
+    if fused is not None and (opacity_reg > 0.0 or scale_reg > 0.0):
+        raise RuntimeError(
+            "train_step: opacity_reg / scale_reg reach the parameters outside the rasterizer; "
+            "optimizer-in-backward (FusedAdam.fuse_into_backward, GatherRowsSync) would apply them "
+            "in a second Adam step. Disable the fusion for this preset.")
+    # reference order on the steps where the strategy edits parameters: backward -> strategy ->
+    # optimizer (runner.py:638-679); the fused update would land before the strategy
+    ordered = fused is not None and strategy is not None and strategy.mutates_params(step)
+    if ordered:
+        _R.set_backward_optimizer(None)
+    try:
+        one = unit_gradient(loss.device)
+        loss.backward(one if one.dtype == loss.dtype else None)          # runner.py:547 (root
+        # gradient handed over instead of a ones_like + fill launch per step)
+    finally:
+        if ordered:
+            _R.set_backward_optimizer(fused)
     if grad_sync is not None:
         grad_sync()
     if strategy is not None:                                             # runner.py:639-658

@@ -160,6 +160,16 @@ class DefaultStrategy:
         assert self.key_for_gradient in info, "The 2D means of the Gaussians is required but missing."
         info[self.key_for_gradient].retain_grad()
 
+    def mutates_params(self, step: int) -> bool:
+        """True on the steps whose step_post_backward edits parameters / optimizer state
+        (refine and opacity-reset steps): those must run strategy-before-optimizer as in
+        runner.py:638-679, so the optimizer-in-backward fusion is suspended for them."""
+        if step >= self.refine_stop_iter:
+            return False
+        refine = (step > self.refine_start_iter and step % self.refine_every == 0
+                  and step % self.reset_every >= self.pause_refine_after_reset)
+        return refine or (step % self.reset_every == 0 and step > 0)
+
     def step_post_backward(self, params, optimizers, state, step: int, info: Dict[str, Any],
                            packed: bool = False) -> None:
         if step >= self.refine_stop_iter:
@@ -423,6 +433,11 @@ class MCMCStrategy:
             g.manual_seed(self.seed)
             state["generator"] = g
         return state["generator"]
+
+    def mutates_params(self, step: int) -> bool:
+        """Position noise is injected on every step, computed from the pre-update parameters
+        (runner.py:649-656 before 676-679): never compatible with optimizer-in-backward."""
+        return True
 
     def step_post_backward(self, params, optimizers, state, step: int, info, lr: float, **_) -> None:
         dev = params["means"].device

@@ -115,6 +115,26 @@ def cpu_baseline(sample_n: int = 250_000, budget_s: float = 150.0):
                        f"scaled x{sample_n}/{N_GAUSS}")}
 
 
+def _self_launch(n: int) -> int:
+    import socket
+    import subprocess
+
+    import torch                      # device_count() does not initialise HIP on this image
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("GSR_BENCH_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {n} but only {have} ROCm device(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+           *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +154,12 @@ def main():
                     help="time fwd+bwd only (the reported line always includes Adam)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD
+        # process and before this process has touched HIP (never re-exec a process that has
+        # initialised the GPU), relay rank 0's JSON line and exit with the job's code.
+        sys.exit(_self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -142,7 +168,10 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}; launch with "
+                 f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}` "
+                 "or run `python bench.py --gpus N` without RANK/WORLD_SIZE in the environment")
     # rehearsal knobs for a 1-GPU box: GSR_BENCH_SINGLE_DEVICE=1 puts every rank on device 0,
     # GSR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
     if os.environ.get("GSR_BENCH_SINGLE_DEVICE") == "1":

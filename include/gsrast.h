@@ -116,6 +116,20 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
 int gsr_pack_grad_rows(int64_t n, const float *grad_rows /* [n,16] */, const int32_t *radii,
                        float *packed, void *stream);
 
+/* gsr_project_bwd over gathered PACKED rows (grad_stride = GSR_PACKED_ROW, radii NULL:
+ * visibility from the row) or scratch rows (GSR_GRAD_ROW, radii required): the non-fused
+ * companion of gsr_project_bwd_adam for the steps on which something must see the parameter
+ * gradients between backward and optimizer step (the densification strategy on refine /
+ * reset steps, runner.py:638-679). Colour-only views (no depth / compensation gradients). */
+int gsr_project_bwd_rows(int C, int N, const float *means, const float *quats, const float *scales,
+                         const float *viewmats, const float *Ks, const float *campos, int width,
+                         int height, float eps2d, int sh_degree, const float *sh0, int sh0_stride,
+                         const float *shN, int shN_stride, const int32_t *radii,
+                         const float *grad_rows, int grad_stride, float *v_means, float *v_quats,
+                         float *v_scales, float *v_sh0, int v_sh0_stride, float *v_shN,
+                         int v_shN_stride, int sh_K, int activations, const float *opacities_act,
+                         float *v_opacities, void *stream);
+
 /* Optimizer in backward (A8 fused into the backward of A1+A3+A4): gsr_project_bwd and
  * gsr_adam_step in ONE pass over the parameters, for the single-process case where nothing
  * (no all-reduce, no other loss term) has to see the parameter gradients. params /

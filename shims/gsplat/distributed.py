@@ -33,10 +33,18 @@ def _worker(local_rank, fn, world_size, args, port, world_rank=None):
     dist.init_process_group("nccl", rank=world_rank, world_size=world_size,
                             device_id=torch.device("cuda", local_rank))
     try:
-        return fn(local_rank, world_rank, world_size, args)
-    finally:
-        dist.barrier()
-        dist.destroy_process_group()
+        out = fn(local_rank, world_rank, world_size, args)
+    except BaseException:
+        # a failing rank must not wait in a barrier the healthy ranks never reach (they would
+        # block in their own collectives): tear the group down and re-raise so that the
+        # launcher (mp.spawn / torchrun) ends the whole job with a non-zero code
+        try:
+            dist.destroy_process_group()
+        finally:
+            raise
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
 
 
 def cli(fn, args, verbose: bool = False):

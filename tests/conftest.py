@@ -21,3 +21,8 @@ def pkg():
 @pytest.fixture(scope="session")
 def rendering():
     return importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    from tests import parity_log
+    parity_log.dump()

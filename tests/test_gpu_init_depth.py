@@ -220,12 +220,15 @@ def test_get_pts_from_depth_vs_oracle_chain(subsample, aligner):
            else IO.adaptive_mask((H, W, 3), out_depth.clone(), omask))
     pts_o, mask_o = IO.assemble_mask_and_unproject(out_depth, omask, sub, K, c2w, co,
                                                    depth_grad_mask_thresh=0.5)
-    agree = (fmask == mask_o).float().mean().item()
-    assert agree > 0.9999, f"mask agreement {agree}"
-    if torch.equal(fmask, mask_o):
-        extent = pts_o.abs().max()
-        assert (pts.cpu() - pts_o).abs().max() <= 3e-3 * extent      # scale/shift differ ~1e-3 (ransac)
-        assert torch.equal(rgbs.cpu(), rgb.view(-1, 3)[mask_o])
+    differing = int((fmask != mask_o).sum())
+    assert differing <= max(1, int(1e-4 * H * W)), f"{differing} mask pixels differ"
+    # points on EVERY pixel both sides kept (never skipped)
+    common = fmask & mask_o
+    rows_h = (torch.cumsum(fmask.long(), 0) - 1)[common]
+    rows_o = (torch.cumsum(mask_o.long(), 0) - 1)[common]
+    extent = pts_o.abs().max()
+    assert (pts.cpu()[rows_h] - pts_o[rows_o]).abs().max() <= 3e-3 * extent      # scale/shift differ ~1e-3 (ransac)
+    assert torch.equal(rgbs.cpu()[rows_h], rgb.view(-1, 3)[mask_o][rows_o])
     assert pts.shape[0] == int(fmask.sum()) and pts.shape[0] > 500
 
 
@@ -309,3 +312,142 @@ def test_metric3d_pre_post_processing_vs_oracle(size):
     assert pred.normal.shape == (H, W, 3) and torch.allclose(pred.normal.cpu(), n_ref, rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError):
         M.Metric3d(None, "cuda")                              # no silent torch.hub fetch
+
+
+# --------------------------------------------------------------------------------------------- #
+# B1 / B4 / B8 / B9 against outputs of the REFERENCE's own points_from_depth.py / pipeline.py
+# (tests/golden/points_golden.npz, generated by tests/golden/make_points_golden.py)
+# --------------------------------------------------------------------------------------------- #
+from tests import points_golden as PG  # noqa: E402
+
+
+@pytest.mark.parametrize("i", range(int(PG.G["b1_n"])))
+def test_b1_project_sfm_vs_reference_golden(i):
+    PF = mod("depth_prediction.points_from_depth")
+    sc = PG.scene(f"b1_{i}")
+    H, W = sc["depth"].shape
+    cg, dg = PF.project_and_filter_sfm_pts(None, sc["sfm"].cuda(), sc["P"].cuda(), (W, H),
+                                           _pd(sc["depth"], sc["mask"]))
+    assert cg.dtype == torch.int64 and torch.equal(cg.cpu(), PG.t(f"b1_{i}_coords"))     # bit-exact
+    assert torch.allclose(dg.cpu(), PG.t(f"b1_{i}_depths"), rtol=1e-6, atol=1e-6)
+
+
+def test_b1_low_confidence_branch_vs_reference_golden():
+    PF = mod("depth_prediction.points_from_depth")
+    sc = PG.scene("b1_err")               # the reference raised on exactly this input
+    with pytest.raises(mod("depth_alignment").LowDepthAlignmentConfidenceError):
+        PF.project_and_filter_sfm_pts(None, sc["sfm"].cuda(), sc["P"].cuda(), (96, 64),
+                                      _pd(sc["depth"], sc["mask"]))
+
+
+@pytest.mark.parametrize("i", range(int(PG.G["b8_n"])))
+def test_b8_depth_gradient_mask_vs_reference_golden(i):
+    PF = mod("depth_prediction.points_from_depth")
+    d = PG.scene(f"b8_{i}")["depth"]
+    m = PF.depth_gradient_mask(d.cuda(), float(PG.G[f"b8_{i}_thr"]))
+    assert torch.equal(m.cpu(), PG.t(f"b8_{i}_mask"))                                    # bit-exact
+
+
+def _hip_cfg(i):
+    cfgm, dac = mod("config"), mod("depth_alignment.config")
+    aligner, factor, grad_thr, nsfm = PG.b9_cfg(i)
+    cfg = cfgm.Config()
+    cfg.mdi.alignment.aligner = dac.DepthAlignmentStrategyEnum[aligner]
+    cfg.mdi.subsample_factor = factor
+    cfg.mdi.depth_grad_mask_thresh = grad_thr
+    cfg.mdi.use_num_sfm_points_mask = nsfm
+    return cfg, aligner
+
+
+class _GoldenParser:
+    """The attributes get_pts_from_depth reads from the reference's Parser
+    (points_from_depth.py:233-237)."""
+
+    def __init__(self, name, pts):
+        self.points = pts.numpy()
+        self.point_indices = {name: np.arange(pts.shape[0])}
+
+
+@pytest.mark.parametrize("i", range(int(PG.G["b9_n"])))
+def test_b4_pipeline_noseg_vs_reference_golden(i):
+    """DepthAlignmentPipeline.align (no segmenter) against the reference's aligned depth map
+    and result mask. lstsqrs: fp32 LSQ accuracy; ransac/msac: the tolerance of the pinned
+    RANSAC test (consensus set reproduced, LSQ in fp64 here vs fp32 einsum + pinv there)."""
+    PF = mod("depth_prediction.points_from_depth")
+    types = mod("types")
+    sc = PG.scene(f"b9_{i}")
+    cfg, aligner = _hip_cfg(i)
+    H, W = sc["depth"].shape
+    pd = _pd(sc["depth"], sc["mask"])
+    co, de = PF.project_and_filter_sfm_pts(None, sc["sfm"].cuda(), sc["P"].cuda(), (W, H), pd)
+    image = types.InputImage(data=sc["rgb"], name="img0", cam2world=sc["c2w"], K=sc["K"])
+    torch.manual_seed(int(PG.G[f"b9_{i}_rng_seed"]))
+    res = PF.DepthAlignmentPipeline.from_config(cfg).align(image, pd, co, de, cfg, None)
+    tol = 1e-5 if aligner == "lstsqrs" else 2e-3
+    lattice = res.aligned_depth[::PG.SUB[0], ::PG.SUB[1]].cpu()
+    assert torch.allclose(lattice, PG.t(f"b9_{i}_aligned"), rtol=tol, atol=tol)
+    assert float(res.aligned_depth.double().sum()) == pytest.approx(float(PG.G[f"b9_{i}_aligned_sum"]), rel=tol)
+    assert torch.equal(res.mask.flatten().cpu(), PG.bits(f"b9_{i}_align_mask", H * W))    # bit-exact
+
+
+@pytest.mark.parametrize("i", range(int(PG.G["b9_n"])))
+def test_b9_masks_and_unprojection_on_the_reference_aligned_depth(i):
+    """Integer work given IDENTICAL inputs: every mask kernel and the compaction are fed the
+    reference's own aligned depth map (reproduced bit for bit by the pinned oracle and checked
+    against the fixture's lattice + sum), so the final mask must be torch.equal to the
+    reference's and the point comparison is never skipped."""
+    PF = mod("depth_prediction.points_from_depth")
+    S = mod("depth_subsampling")
+    from tests.test_points_oracle_golden import _oracle_chain
+    sc, co, out_depth, omask, (factor, grad_thr, nsfm) = _oracle_chain(i)
+    H, W = out_depth.shape
+    assert torch.equal(out_depth[::PG.SUB[0], ::PG.SUB[1]], PG.t(f"b9_{i}_aligned"))
+    assert float(out_depth.double().sum()) == pytest.approx(float(PG.G[f"b9_{i}_aligned_sum"]), rel=1e-12)
+    cfg, _ = _hip_cfg(i)
+    depth_g, mask_g = out_depth.cuda(), omask.cuda()
+    sub = PF.get_subsampler(cfg).get_mask(sc["rgb"].cuda(), depth_g, mask_g)
+    extra = None
+    if grad_thr is not None:
+        extra = PF.depth_gradient_mask(depth_g, grad_thr).flatten()
+    if nsfm:
+        m = S.num_sfm_points_mask(co.cuda(), (H, W), cfg.mdi.num_sfm_points_mask).flatten()
+        extra = m if extra is None else (extra & m)
+    pts, rgbs, fmask = PF.unproject_masked(depth_g, mask_g, sub, extra, sc["rgb"].cuda(), sc["K"], sc["c2w"])
+    ref_mask = PG.bits(f"b9_{i}_final_mask", H * W)
+    assert torch.equal(fmask.cpu(), ref_mask)                                            # bit-exact
+    ref_pts = PG.t(f"b9_{i}_pts")
+    assert pts.shape == ref_pts.shape
+    extent = float(ref_pts.abs().max())
+    assert float((pts.cpu() - ref_pts).abs().max()) <= 1e-5 * extent
+    assert torch.equal(rgbs.cpu(), sc["rgb"].view(-1, 3)[ref_mask])
+
+
+@pytest.mark.parametrize("i", range(int(PG.G["b9_n"])))
+def test_b9_get_pts_from_depth_vs_reference_golden(i):
+    """The whole chain through the reference's own signature
+    `get_pts_from_depth(predicted_depth, image, parser, config, device, debug_export_dir)`.
+    The aligned depth differs from the reference's in the last bits (fp64 vs fp32 LSQ sums), so
+    a pixel sitting exactly on a stride / threshold boundary may change sides: the masks must
+    agree on all but <= 1e-4 of the pixels and the points are compared on EVERY common pixel."""
+    PF = mod("depth_prediction.points_from_depth")
+    types = mod("types")
+    sc = PG.scene(f"b9_{i}")
+    cfg, aligner = _hip_cfg(i)
+    H, W = sc["depth"].shape
+    image = types.InputImage(data=sc["rgb"], name="img0", cam2world=sc["c2w"], K=sc["K"])
+    torch.manual_seed(int(PG.G[f"b9_{i}_rng_seed"]))
+    pts, fmask, P = PF.get_pts_from_depth(_pd(sc["depth"], sc["mask"]), image,
+                                          _GoldenParser("img0", sc["sfm"]), cfg, "cuda", None)
+    assert torch.allclose(P.cpu(), PG.t(f"b9_{i}_P"), rtol=1e-6, atol=1e-6)
+    ref_mask, ref_pts = PG.bits(f"b9_{i}_final_mask", H * W), PG.t(f"b9_{i}_pts")
+    differing = int((fmask != ref_mask).sum())
+    from tests import parity_log
+    parity_log.record("init_chain", case=i, aligner=aligner, pixels=H * W, mask_pixels_differing=differing,
+                      points=int(fmask.sum()), points_reference=int(ref_mask.sum()))
+    assert differing <= max(1, int(1e-4 * H * W)), f"{differing} mask pixels differ"
+    common = fmask & ref_mask
+    rows_h = (torch.cumsum(fmask.long(), 0) - 1)[common]
+    rows_r = (torch.cumsum(ref_mask.long(), 0) - 1)[common]
+    assert rows_h.numel() > 300
+    tol = (1e-5 if aligner == "lstsqrs" else 3e-3) * float(ref_pts.abs().max())
+    assert float((pts.cpu()[rows_h] - ref_pts[rows_r]).abs().max()) <= tol

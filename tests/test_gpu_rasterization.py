@@ -12,13 +12,14 @@ import pytest
 import torch
 
 from oracle import rasterization_oracle as O
-from tests import scenes
+from tests import parity_log, scenes
 
 pytestmark = pytest.mark.gpu
 
 IMG_ATOL = 1e-4
 FLIP_ATOL = 5e-3          # one threshold-boundary contribution (see _check)
 GRAD_RTOL = 1e-3
+PSNR_ATOL_DB = 1e-4       # north_star: "within 1e-4 PSNR" of the reference rasterizer
 
 
 @pytest.fixture(scope="module")
@@ -73,17 +74,30 @@ def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL, mean_
     assert _rel(meta_g["means2d"].detach().cpu()[both], meta_c["means2d"].detach()[both]) < 1e-5
     assert _rel(meta_g["conics"].detach().cpu()[both], meta_c["conics"].detach()[both]) < 1e-3
     for name, got, ref in (("render_colors", rc_g, rc_c), ("render_alphas", ra_g, ra_c)):
-        err = (got.detach().cpu() - ref.detach()).abs()
+        got_c, ref_d = got.detach().cpu(), ref.detach()
+        err = (got_c - ref_d).abs()
         # A pixel-Gaussian pair whose alpha (or next-T) sits within one ulp of a
         # threshold (1/255, 0.999, 1e-4) may be blended by one implementation and
         # skipped by the other (exp rounding): that moves ONE pixel by at most
         # ~alpha*colour = 4e-3. Such flips are allowed on <= 1e-4 of the pixels;
         # everything else must be within img_atol, and the mean error far below it.
         n_bad = int((err > img_atol).sum())
+        flip = FLIP_ATOL * max(1.0, float(ref_d.abs().max()))
+        # north_star's own criterion: the PSNR of the render against a fixed target image
+        # (the training loss's view of the render) moves by <= 1e-4 dB between HIP and oracle
+        target = torch.rand(ref_d.shape, generator=torch.Generator().manual_seed(2)) * float(
+            ref_d.abs().max().clamp_min(1e-6))
+        peak = float(target.max())
+        d_psnr = abs(parity_log.psnr(got_c, target, peak) - parity_log.psnr(ref_d, target, peak))
+        parity_log.record("image", output=name, pixels=err.numel(), n_over_atol=n_bad,
+                          frac_over_atol=n_bad / err.numel(), max_abs_err=float(err.max()),
+                          mean_abs_err=float(err.mean()), psnr_hip_vs_oracle_db=parity_log.psnr(
+                              got_c, ref_d, max(1.0, float(ref_d.abs().max()))),
+                          delta_psnr_vs_target_db=d_psnr, atol=img_atol, flip_frac_allowed=flip_frac)
         assert n_bad <= max(1, math.ceil(flip_frac * err.numel())), f"{name}: {n_bad} px > {img_atol}"
-        flip = FLIP_ATOL * max(1.0, float(ref.detach().abs().max()))
         assert err.max().item() <= flip, f"{name} max abs err {err.max().item():.3e}"
         assert err.mean().item() <= img_atol * mean_frac, f"{name} mean abs err {err.mean().item():.3e}"
+        assert d_psnr <= PSNR_ATOL_DB, f"{name}: PSNR vs target differs by {d_psnr:.2e} dB"
     for k in cpu:
         if cpu[k].grad is None:
             assert gpu[k].grad is None or gpu[k].grad.abs().max().item() == 0.0
@@ -94,9 +108,12 @@ def _check(cpu, gpu, out_c, out_g, img_atol=IMG_ATOL, grad_rtol=GRAD_RTOL, mean_
         # (see above) can touch: a flipped pair adds/removes one O(alpha)
         # contribution to ONE Gaussian's gradients.
         l2 = float((got - ref).norm() / ref.norm().clamp_min(1e-20))
-        assert l2 <= grad_rtol, f"grad {k}: L2 rel err {l2:.3e}"
         tol = grad_rtol * float(ref.abs().max())
         n_bad = int(((got - ref).abs() > tol).sum())
+        parity_log.record("grad", tensor=k, elements=ref.numel(), l2_rel=l2, max_rel=_rel(got, ref),
+                          n_over_rtol=n_bad, frac_over_rtol=n_bad / ref.numel(), rtol=grad_rtol,
+                          flip_frac_allowed=flip_frac)
+        assert l2 <= grad_rtol, f"grad {k}: L2 rel err {l2:.3e}"
         assert n_bad <= max(1, math.ceil(flip_frac * ref.numel())), f"grad {k}: {n_bad} elements off by > {tol:.2e}"
         assert _rel(got, ref) <= 50 * grad_rtol, f"grad {k}: max rel err {_rel(got, ref):.3e}"
 

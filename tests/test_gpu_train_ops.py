@@ -300,3 +300,106 @@ def test_strategy_statistics_kernel_matches_host_formulation():
         assert torch.allclose(got["radii"], r.max(0).values, rtol=1e-6)
         one = vis.sum(0) == 1
         assert torch.allclose(got["radii"][one], ref["radii"][one], rtol=1e-6)
+
+
+def _strategy_run(fused_bwd: bool, steps: int = 70):
+    """Small training run with DefaultStrategy; records, per step, whether the strategy saw
+    parameter gradients (= it ran BEFORE the optimizer, the reference's order)."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
+    S = importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    W, H = 128, 96
+    gt = scenes.make_scene(1500, 7, box=(1.0, 0.7, 0.4), scale_mean=0.04)
+    vms, Ks = scenes.cameras(range(0, 100, 10), width=W, height=H, f=110.0, dist=2.5)
+    c2ws, Ks = torch.linalg.inv(vms).cuda(), Ks.cuda()
+    g = torch.Generator().manual_seed(11)
+    targets = [torch.rand(1, H, W, 3, generator=g).cuda() * 0.5 + 0.25 for _ in range(10)]
+    n0 = 800
+    pts = gt["means"][:n0] + 0.02 * torch.randn(n0, 3, generator=g)
+    splats, opts = runner.create_splats_with_optimizers(
+        pts, torch.rand(n0, 3, generator=g), torch.log(gt["scales"][:n0]), quats=gt["quats"][:n0],
+        init_opacity=0.3)
+    fused = optim.FusedAdam(opts)
+    strat = S.DefaultStrategy(refine_start_iter=10, refine_every=20, reset_every=45,
+                              refine_stop_iter=200, grow_grad2d=5e-5)
+    st = strat.initialize_state(scene_scale=1.0)
+    seen = []
+    inner = strat.step_post_backward
+
+    def spy(params, optimizers, state, step, info, **kw):
+        seen.append((step, all(p.grad is not None for p in params.values())))
+        return inner(params, optimizers, state, step, info, **kw)
+
+    strat.step_post_backward = spy
+    counts, losses = [], []
+    try:
+        if fused_bwd:
+            fused.fuse_into_backward(True)
+        for step in range(steps):
+            i = step % 10
+            loss, _ = runner.train_step(splats, fused, c2ws[i:i + 1], Ks[i:i + 1], targets[i], step=step,
+                                        strategy=strat, strategy_state=st)
+            counts.append(len(splats["means"]))
+            losses.append(float(loss))
+    finally:
+        R.set_backward_optimizer(None)
+    steps_done = {n: float(fused[n].state[splats[n]]["step"]) for n in ("means", "quats")}
+    return counts, losses, seen, strat, steps_done
+
+
+def test_fused_backward_with_strategy_keeps_reference_order():
+    """VERDICT r1 #10 / ADVICE: with optimizer-in-backward the update lands inside
+    loss.backward(), before strategy.step_post_backward, whereas the reference runs the
+    strategy first (runner.py:638-679). train_step suspends the fusion on exactly the steps
+    on which the strategy edits parameters (3 refine cycles + 1 opacity reset here), so on
+    those steps the strategy sees the gradients and the run matches the unfused one."""
+    c_sep, l_sep, seen_sep, strat, n_sep = _strategy_run(False)
+    c_fus, l_fus, seen_fus, _, n_fus = _strategy_run(True)
+    ordered = [s for s in range(70) if strat.mutates_params(s)]
+    assert ordered == [20, 40, 45, 60], ordered
+    assert all(flag for _, flag in seen_sep)                       # unfused: always strategy first
+    for step, flag in seen_fus:                                    # fused: exactly the ordered steps
+        assert flag == (step in ordered), (step, flag)
+    assert n_fus == n_sep == {"means": 70.0, "quats": 70.0}        # one Adam step per iteration
+    assert c_sep[-1] != c_sep[0], "densification never changed the Gaussian count"
+    # identical decisions up to the (atomic-order) noise of the compositing backward
+    for a, b in zip(c_sep, c_fus):
+        assert abs(a - b) <= max(2, 0.01 * a), (c_sep, c_fus)
+    assert abs(l_sep[-1] - l_fus[-1]) <= 0.02 * abs(l_sep[-1])
+
+
+def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
+    """the MCMC preset's opacity / scale regularisers reach the parameters
+    outside the rasterizer; with optimizer-in-backward they used to be applied in a SECOND Adam
+    step. train_step now raises, and FusedAdam.step() raises on any stray gradient."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 500
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 64, 48
+    vm, K = scenes.cameras([0], width=W, height=H, f=60.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    splats, opts = runner.create_splats_with_optimizers(
+        sc["means"], torch.rand(N, 3), torch.log(sc["scales"]), quats=sc["quats"])
+    fused = optim.FusedAdam(opts)
+    fused.fuse_into_backward(True)
+    try:
+        with pytest.raises(RuntimeError, match="opacity_reg"):
+            runner.train_step(splats, fused, c2w, K, target, step=5000, opacity_reg=0.01)
+        # a loss term added by hand
+        renders, _, _ = runner.rasterize_splats(splats, c2w, K, W, H, sh_degree=3)
+        loss = (renders - target).abs().mean() + 0.01 * torch.sigmoid(splats["opacities"]).mean()
+        loss.backward()
+        with pytest.raises(RuntimeError, match="outside the rasterizer"):
+            fused.step()
+        fused.zero_grad()
+        # and the plain fused step still works afterwards
+        runner.train_step(splats, fused, c2w, K, target, step=5000)
+        assert float(fused["means"].state[splats["means"]]["step"]) == 2.0
+    finally:
+        R.set_backward_optimizer(None)

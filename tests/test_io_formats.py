@@ -44,7 +44,7 @@ def test_depth_cache_roundtrip(tmp_path):
         "3dgs_monocular_depth_init_amd.depth_prediction.predictors.depth_predictor_interface").PredictedDepth
     pred = PD(depth=torch.rand(4, 5), mask=torch.rand(4, 5) > 0.5, depth_confidence=torch.rand(4, 5))
     path = IO.depth_cache_path(tmp_path, "Metric3d_vits", "garden", "DSC0001.JPG")
-    assert path.name == "DSC0001.pth" and path.parent.name == "garden"
+    assert path.name == "DSC0001.JPG.pth" and path.parent.name == "garden"    # monocular_depth_init.py:71
     IO.save_predicted_depth(pred, path)
     back = IO.load_predicted_depth(path)
     assert torch.equal(back.depth, pred.depth) and torch.equal(back.mask, pred.mask)
