@@ -14,8 +14,9 @@ that do not exist here (gsplat, pointcloud_subsampling, pycolmap, cv2, imageio,
 segment_anything, skimage, nerfbaselines, open3d) -- as type names, dataset loaders,
 segmenters and debug exporters, none of which the recorded functions execute (the
 parser is duck-typed: `.points`, `.point_indices[name]`; segmenter=None; no debug dir).
-Inputs are not stored: tests regenerate them with make_points_golden_scene.camera_scene
-(our own seeded generator) and check float64 checksums recorded here.
+The seeded inputs (our own generator, make_points_golden_scene.py) are stored next to the
+outputs -- depth, packed mask, SfM points, P, K, c2w; the colours are exact integer arithmetic
+(scene_rgb) and are rebuilt by the tests.
 As SURVEY.md section 8c proposes, this script -- and only this script, which never
 travels or ships -- registers INERT placeholder modules for those nine names so that
 the import succeeds. No functionality of those packages is emulated and nothing a
@@ -84,23 +85,24 @@ class _Parser:
 SUB = (5, 7)
 
 
-def _checksums(sc):
-    """float64 sums of the regenerated inputs: the test asserts that camera_scene() reproduced them."""
-    return np.array([sc[k].double().sum().item() for k in ("depth", "mask", "rgb", "sfm", "P")], np.float64)
+def _store(key, sc):
+    out[f"{key}_depth"] = sc["depth"].numpy()
+    out[f"{key}_mask"] = np.packbits(sc["mask"].numpy())
+    for k in ("sfm", "P", "K", "c2w"):
+        out[f"{key}_{k}"] = sc[k].numpy()
 
 
 out = {}
 quiet = contextlib.redirect_stdout(io.StringIO())
 
 # ---- B1: reprojection + validity filter ------------------------------------------------------
-b1_cases = [(64, 96, 400, 0.15, 40), (270, 480, 3000, 0.3, 41), (48, 40, 50, 0.0, 42)]
+b1_cases = [(64, 96, 400, 0.15, 40), (135, 240, 1500, 0.3, 41), (48, 40, 50, 0.0, 42)]
 for i, (H, W, M, frac_out, seed) in enumerate(b1_cases):
     sc = camera_scene(H, W, M, seed, frac_outside=frac_out)
     pd = PredictedDepth(depth=sc["depth"].clone(), mask=sc["mask"].clone())
     with quiet:
         coords, depths = pfd.project_and_filter_sfm_pts(sc["rgb"], sc["sfm"].clone(), sc["P"], (W, H), pd, None)
-    out[f"b1_{i}_scene"] = np.array([H, W, M, seed, frac_out], np.float64)     # camera_scene(...) arguments
-    out[f"b1_{i}_check"] = _checksums(sc)
+    _store(f"b1_{i}", sc)
     out[f"b1_{i}_coords"] = coords.numpy()
     out[f"b1_{i}_depths"] = depths.numpy()
 # the error branch: most points behind / outside the camera
@@ -113,26 +115,27 @@ try:
 except LowDepthAlignmentConfidenceError:
     raised = True
 assert raised
-out["b1_err_scene"] = np.array([64, 96, 200, 43, 0.9], np.float64)
+_store("b1_err", sc)
 out["b1_n"] = np.int64(len(b1_cases))
 
 # ---- B8: depth-gradient mask -----------------------------------------------------------------
-b8_cases = [(64, 96, 50, 0.05), (270, 480, 51, 0.02), (33, 17, 52, 0.2)]
+b8_cases = [(64, 96, 50, 0.05), (135, 240, 51, 0.02), (33, 17, 52, 0.2)]
 for i, (H, W, seed, thr) in enumerate(b8_cases):
     d = camera_scene(H, W, 10, seed)["depth"]
-    out[f"b8_{i}_scene"] = np.array([H, W, 10, seed, 0.1], np.float64)
+    out[f"b8_{i}_depth"] = d.numpy()
     out[f"b8_{i}_thr"] = np.float64(thr)
-    out[f"b8_{i}_mask"] = pfd.depth_gradient_mask(d.clone(), thr).numpy()
+    out[f"b8_{i}_gradmask"] = pfd.depth_gradient_mask(d.clone(), thr).numpy()
 out["b8_n"] = np.int64(len(b8_cases))
 
 # ---- B4 + B9: no-segmentation alignment and the full get_pts_from_depth chain ------------------
+stored = {}
 b9_cases = [
     # (H, W, M, seed, rng_seed, aligner, subsample_factor, grad_thresh, use_num_sfm_mask)
     (64, 96, 400, 60, 70, "lstsqrs", 4, None, False),
     (64, 96, 400, 60, 70, "ransac", 4, None, True),
     (270, 480, 3000, 61, 71, "msac", 10, None, True),
     (270, 480, 3000, 61, 71, "ransac", "adaptive", None, False),
-    (270, 480, 3000, 62, 72, "lstsqrs", 10, 0.05, True),
+    (135, 240, 1500, 62, 72, "lstsqrs", 10, 0.05, True),
     (135, 240, 1500, 63, 73, "ransac", "adaptive", 0.1, True),
 ]
 for i, (H, W, M, seed, rng_seed, aligner, factor, grad_thr, nsfm) in enumerate(b9_cases):
@@ -158,8 +161,10 @@ for i, (H, W, M, seed, rng_seed, aligner, factor, grad_thr, nsfm) in enumerate(b
     with quiet:
         torch.manual_seed(rng_seed)
         pts, mask, P = pfd.get_pts_from_depth(pd, image, _Parser("img0", sc["sfm"]), cfg, "cpu", None)
-    out[f"b9_{i}_scene"] = np.array([H, W, M, seed, 0.1], np.float64)
-    out[f"b9_{i}_check"] = _checksums(sc)
+    if (H, W, M, seed) not in stored:
+        stored[(H, W, M, seed)] = i
+        _store(f"b9_{i}", sc)
+    out[f"b9_{i}_scene_of"] = np.int64(stored[(H, W, M, seed)])     # cases sharing one stored scene
     out[f"b9_{i}_cfg"] = np.array([aligner, str(factor), str(grad_thr), str(int(nsfm))])
     out[f"b9_{i}_rng_seed"] = np.int64(rng_seed)
     out[f"b9_{i}_pts"] = pts.numpy()

@@ -1,4 +1,6 @@
 """Seeded synthetic camera + depth + SfM scene for make_points_golden.py (no reference code).
+The generated inputs are STORED in the fixture (depth, mask, SfM points, P, K, c2w): torch's
+randn and matmul are not bit-reproducible across CPU models, the tests must not depend on that.
 
 SfM points are placed so that they reproject to (integer pixel + U(-0.4, 0.4)): the rounded
 pixel does not depend on the last bits of the projection arithmetic, so integer outputs of
@@ -6,6 +8,11 @@ the reference (CPU torch) and of the HIP kernels can be compared bit for bit."""
 import math
 
 import torch
+
+
+def scene_rgb(H, W):
+    y, x, c = torch.meshgrid(torch.arange(H), torch.arange(W), torch.arange(3), indexing="ij")
+    return ((x * 7 + y * 13 + c * 29) % 256).float() / 255.0
 
 
 def camera_scene(H, W, M, seed, frac_outside=0.1, outlier_frac=0.2, noise=0.02):
@@ -16,7 +23,9 @@ def camera_scene(H, W, M, seed, frac_outside=0.1, outlier_frac=0.2, noise=0.02):
     # a few depth edges so that the gradient mask has something to reject
     depth[H // 3: H // 2, W // 4: W // 2] += 1.5
     mask = torch.rand(H, W, generator=g) > 0.05
-    rgb = torch.rand(H, W, 3, generator=g)
+    # colours by exact integer arithmetic (no RNG, identical on every CPU): tests rebuild them
+    # with scene_rgb(H, W) instead of storing 3 floats per pixel
+    rgb = scene_rgb(H, W)
     f = 0.9 * W
     K = torch.tensor([[f, 0.0, W / 2 + 0.3], [0.0, 1.05 * f, H / 2 - 0.2], [0.0, 0.0, 1.0]])
     ax, ay, az = (0.2 * torch.rand(3, generator=g) - 0.1).tolist()

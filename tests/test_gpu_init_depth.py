@@ -345,7 +345,7 @@ def test_b8_depth_gradient_mask_vs_reference_golden(i):
     PF = mod("depth_prediction.points_from_depth")
     d = PG.scene(f"b8_{i}")["depth"]
     m = PF.depth_gradient_mask(d.cuda(), float(PG.G[f"b8_{i}_thr"]))
-    assert torch.equal(m.cpu(), PG.t(f"b8_{i}_mask"))                                    # bit-exact
+    assert torch.equal(m.cpu(), PG.t(f"b8_{i}_gradmask"))                                    # bit-exact
 
 
 def _hip_cfg(i):

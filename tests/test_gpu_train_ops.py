@@ -362,7 +362,10 @@ def test_fused_backward_with_strategy_keeps_reference_order():
     assert all(flag for _, flag in seen_sep)                       # unfused: always strategy first
     for step, flag in seen_fus:                                    # fused: exactly the ordered steps
         assert flag == (step in ordered), (step, flag)
-    assert n_fus == n_sep == {"means": 70.0, "quats": 70.0}        # one Adam step per iteration
+    # one Adam step per iteration, except the 3 refine steps: the strategy replaces the
+    # parameters there, the new tensors carry no gradient and the optimizer skips them -- in
+    # the reference's loop as well (runner.py:676-679 after 639-647)
+    assert n_fus == n_sep == {"means": 67.0, "quats": 67.0}
     assert c_sep[-1] != c_sep[0], "densification never changed the Gaussian count"
     # identical decisions up to the (atomic-order) noise of the compositing backward
     for a, b in zip(c_sep, c_fus):

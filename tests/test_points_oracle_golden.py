@@ -28,7 +28,7 @@ def test_b1_low_confidence_error_branch():
 @pytest.mark.parametrize("i", range(int(G["b8_n"])))
 def test_b8_depth_gradient_mask(i):
     d = PG.scene(f"b8_{i}")["depth"]
-    assert torch.equal(IO.depth_gradient_mask(d, float(G[f"b8_{i}_thr"])), PG.t(f"b8_{i}_mask"))
+    assert torch.equal(IO.depth_gradient_mask(d, float(G[f"b8_{i}_thr"])), PG.t(f"b8_{i}_gradmask"))
 
 
 def _oracle_chain(i):

@@ -1,14 +1,22 @@
 // VALU issue-rate microbenchmark for gfx950 (evidence for DESIGN.md section 4 / bench.py's
 // `valu_issue`): cycles per wave64 VALU instruction per SIMD for instruction streams of
-// different dependency structure, swept over waves per SIMD, with the shader clock MEASURED
-// in the kernel (delta s_memtime / delta s_memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS
-// item 6) instead of assumed. Prints one JSON object per (mode, waves/SIMD).
+// different dependency structure, at a CONTROLLED number of waves per SIMD.
 //
-//   hipcc -O3 --offload-arch=gfx950 tools/ubench/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// Placement: ONE workgroup of 64*4*w threads on one CU puts exactly w waves on each of the
+// CU's 4 SIMDs (a workgroup's waves are dealt round-robin to the SIMDs); a grid of many small
+// workgroups, as used first, leaves the per-SIMD count to the dispatcher and made the rates
+// unreadable. The rate is taken inside the kernel: every wave stamps s_memtime before and
+// after its loop, rate = (last end - first start) / (instructions per wave * w).
+// The shader clock is MEASURED (delta s_memtime / delta s_memrealtime x 100 MHz,
+// MI355X_MICROARCH.md DVFS item 6), both for the idle chip (one workgroup) and with all
+// 256 CUs running the same loop (`loaded`).
+//
+//   hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize tools/ubench/valu_rate.hip -o valu_rate
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK(x)                                                                       \
@@ -20,30 +28,38 @@
     }                                                                                  \
   } while (0)
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 enum Mode {
   INDEP_FMA = 0,   // 16 independent v_fma_f32 per trip
   CHAIN1,          // one dependent chain through all 16
   CHAIN2,          // two interleaved chains
-  CHAIN4,          // four interleaved chains
-  MUL_CMP_CND,     // v_mul + v_cmp + v_cndmask, independent
+  MUL_CMP_CND,     // v_mul + v_cmp + v_cndmask (VCC hazard: s_nop between cmp and cndmask)
   EXP_QUARTER,     // 1/4 v_exp_f32, 3/4 v_fma_f32, independent
+  PK_FMA,          // 8 independent v_pk_fma_f32 (16 fp32 fmas) per trip
+  PK_CHAIN,        // 8 v_pk_fma_f32 in one dependent chain
   COMPOSITE1,      // the compositing body's shape: sigma -> exp -> alpha -> T chain, one Gaussian
   COMPOSITE2,      // the same, two Gaussians per trip (two independent sigma/exp/alpha chains)
   N_MODES
 };
-static const char *kName[N_MODES] = {"indep_fma",   "chain1",      "chain2",     "chain4",
-                                     "mul_cmp_cnd", "exp_quarter", "composite1", "composite2"};
-// VALU instructions per loop trip (checked against the ISA: --save-temps and count)
-static const int kInsts[N_MODES] = {16, 16, 16, 16, 48, 16, 0, 0};
+static const char *kName[N_MODES] = {"indep_fma", "chain1",   "chain2",     "mul_cmp_cnd", "exp_quarter",
+                                     "pk_fma",    "pk_chain", "composite1", "composite2"};
 
 template <int MODE>
-__global__ void __launch_bounds__(64) k(float *out, unsigned long long *stamps, int iters, float a,
-                                        float b) {
+__global__ void __launch_bounds__(1024) k(float *out, unsigned long long *stamps, int iters, float a_,
+                                          float b_) {
   float r[16];
+  // loop constants in VGPRs (an SGPR operand pair would hit the constant-bus limit)
+  const float a = a_ + threadIdx.x * 1e-9f, b = b_ + threadIdx.x * 1e-9f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 0.001f + i;
+  f2 p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = f2{r[2 * i], r[2 * i + 1]};
+  const f2 pa = f2{a, a}, pb = f2{b, b};
   float T = 1.0f, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-  unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
     if constexpr (MODE == COMPOSITE1 || MODE == COMPOSITE2) {
       constexpr int G = MODE == COMPOSITE1 ? 1 : 2;
@@ -63,7 +79,13 @@ __global__ void __launch_bounds__(64) k(float *out, unsigned long long *stamps, 
         acc1 = __builtin_fmaf(w, r[13], acc1);
         acc2 = __builtin_fmaf(w, r[14], acc2);
         T = T - w;
-        r[0 + g] += 1e-7f;  // keep the loads "live": next Gaussian's parameters differ
+        r[0 + g] += 1e-7f;  // the next Gaussian's parameters differ
+      }
+    } else if constexpr (MODE == PK_FMA || MODE == PK_CHAIN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (MODE == PK_FMA) p[i] = __builtin_elementwise_fma(p[i], pa, pb);
+        if (MODE == PK_CHAIN) p[i] = __builtin_elementwise_fma(p[(i + 7) & 7], pa, p[i]);
       }
     } else {
 #pragma unroll
@@ -71,7 +93,6 @@ __global__ void __launch_bounds__(64) k(float *out, unsigned long long *stamps, 
         if (MODE == INDEP_FMA) r[i] = __builtin_fmaf(r[i], a, b);
         if (MODE == CHAIN1) r[i] = __builtin_fmaf(r[(i + 15) & 15], a, r[i]);
         if (MODE == CHAIN2) r[i] = __builtin_fmaf(r[(i + 14) & 15], a, r[i]);
-        if (MODE == CHAIN4) r[i] = __builtin_fmaf(r[(i + 12) & 15], a, r[i]);
         if (MODE == MUL_CMP_CND) {
           float t = r[i] * a;
           r[i] = t > b ? t : r[i];
@@ -81,57 +102,69 @@ __global__ void __launch_bounds__(64) k(float *out, unsigned long long *stamps, 
       }
     }
   }
-  unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
   float s = T + acc0 + acc1 + acc2;
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += r[i];
-  out[blockIdx.x * 64 + threadIdx.x] = s;
-  if (threadIdx.x == 0) {
-    stamps[2 * blockIdx.x] = c1 - c0;      // shader cycles
-    stamps[2 * blockIdx.x + 1] = w1 - w0;  // 100 MHz ticks
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += p[i].x + p[i].y;
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) {
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    stamps[4 * w + 0] = c0;
+    stamps[4 * w + 1] = c1;
+    stamps[4 * w + 2] = w0;
+    stamps[4 * w + 3] = w1;
   }
 }
 
 template <int MODE>
 int run(int insts_per_iter) {
-  const int max_blocks = 1024 * 8;
+  if (insts_per_iter <= 0) return 0;
+  const int max_blocks = 256 * 2;
   float *out;
   unsigned long long *stamps;
-  CHECK(hipMalloc(&out, sizeof(float) * 64 * max_blocks));
-  CHECK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * max_blocks));
-  std::vector<unsigned long long> h(2 * max_blocks);
+  CHECK(hipMalloc(&out, sizeof(float) * 1024 * max_blocks));
+  CHECK(hipMalloc(&stamps, sizeof(unsigned long long) * 4 * 16 * max_blocks));
+  std::vector<unsigned long long> h(4 * 16 * max_blocks);
   const int iters = 40000;
-  for (int wps : {1, 2, 4, 5, 8}) {
-    const int blocks = 1024 * wps;  // 256 CUs x 4 SIMDs x wps waves
-    hipEvent_t e0, e1;
-    CHECK(hipEventCreate(&e0));
-    CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w)  // warm the clock governor
-      hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, out, stamps, iters, 1.0001f, 0.5f);
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, out, stamps, iters, 1.0001f, 0.5f);
-    CHECK(hipEventRecord(e1));
-    CHECK(hipEventSynchronize(e1));
-    float ms;
-    CHECK(hipEventElapsedTime(&ms, e0, e1));
-    CHECK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
-    std::vector<double> ghz(blocks), cyc(blocks);
-    for (int b = 0; b < blocks; ++b) {
-      cyc[b] = (double)h[2 * b];
-      ghz[b] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;
+  for (int loaded = 0; loaded < 2; ++loaded) {
+    for (int w : {1, 2, 4}) {            // waves per SIMD
+      const int threads = 256 * w;       // 4 SIMDs x w waves
+      // loaded: one such workgroup per CU (256) -- at w <= 2 two workgroups could share a CU,
+      // so the per-SIMD figure is taken from each workgroup's own span either way
+      const int blocks = loaded ? 256 : 1;
+      for (int rep = 0; rep < 2; ++rep)
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(threads), 0, 0, out, stamps, iters, 1.0001f, 0.5f);
+      CHECK(hipDeviceSynchronize());
+      const int waves_per_block = threads / 64;
+      CHECK(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 4 * waves_per_block * blocks,
+                      hipMemcpyDeviceToHost));
+      std::vector<double> span(blocks), ghz(blocks), onewave(blocks);
+      for (int b = 0; b < blocks; ++b) {
+        unsigned long long s0 = ~0ull, s1 = 0, wt0 = ~0ull, wt1 = 0;
+        double own = 0;
+        for (int wv = 0; wv < waves_per_block; ++wv) {
+          const unsigned long long *q = &h[4 * ((size_t)b * waves_per_block + wv)];
+          s0 = std::min(s0, q[0]); s1 = std::max(s1, q[1]);
+          wt0 = std::min(wt0, q[2]); wt1 = std::max(wt1, q[3]);
+          own += (double)(q[1] - q[0]);
+        }
+        span[b] = (double)(s1 - s0);
+        ghz[b] = (double)(s1 - s0) / (double)(wt1 - wt0) * 0.1;
+        onewave[b] = own / waves_per_block;
+      }
+      std::sort(span.begin(), span.end());
+      std::sort(ghz.begin(), ghz.end());
+      std::sort(onewave.begin(), onewave.end());
+      const double n_inst = (double)iters * insts_per_iter;
+      printf("{\"mode\": \"%s\", \"chip\": \"%s\", \"waves_per_simd\": %d, \"clock_ghz\": %.3f, "
+             "\"insts_per_trip\": %d, \"cycles_per_inst_per_simd\": %.3f, "
+             "\"cycles_per_inst_one_wave\": %.3f}\n",
+             kName[MODE], loaded ? "all 256 CUs busy" : "one CU", w, ghz[blocks / 2], insts_per_iter,
+             span[blocks / 2] / (n_inst * w), onewave[blocks / 2] / n_inst);
+      fflush(stdout);
     }
-    std::sort(ghz.begin(), ghz.end());
-    std::sort(cyc.begin(), cyc.end());
-    const double clock = ghz[blocks / 2];
-    // a wave's own lifetime in cycles / its instructions, and the per-SIMD aggregate rate
-    const double wave_cpi = cyc[blocks / 2] / ((double)iters * insts_per_iter);
-    const double simd_cpi = ms * 1e-3 * clock * 1e9 / ((double)wps * iters * insts_per_iter);
-    printf("{\"mode\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.4f, \"clock_ghz\": %.3f, "
-           "\"insts_per_trip\": %d, \"cycles_per_inst_per_simd\": %.3f, "
-           "\"cycles_per_inst_one_wave\": %.3f}\n",
-           kName[MODE], wps, ms, clock, insts_per_iter, simd_cpi, wave_cpi);
-    fflush(stdout);
   }
   CHECK(hipFree(out));
   CHECK(hipFree(stamps));
@@ -139,17 +172,19 @@ int run(int insts_per_iter) {
 }
 
 int main(int argc, char **argv) {
-  // instruction counts of the two composite bodies are passed in (counted from the ISA by
-  // tools/ubench/run_valu_rate.sh); the pure modes have fixed counts
-  const int c1 = argc > 1 ? atoi(argv[1]) : 0, c2 = argc > 2 ? atoi(argv[2]) : 0;
+  // VALU instructions per loop trip of every mode, counted from the ISA by
+  // tools/ubench/run_valu_rate.sh (argv[1..N_MODES]); 0 skips a mode
+  int n[N_MODES] = {16, 16, 16, 48, 16, 8, 8, 0, 0};
+  for (int m = 0; m < N_MODES && m + 1 < argc; ++m) n[m] = atoi(argv[m + 1]);
   int rc = 0;
-  rc |= run<INDEP_FMA>(kInsts[INDEP_FMA]);
-  rc |= run<CHAIN1>(kInsts[CHAIN1]);
-  rc |= run<CHAIN2>(kInsts[CHAIN2]);
-  rc |= run<CHAIN4>(kInsts[CHAIN4]);
-  rc |= run<MUL_CMP_CND>(kInsts[MUL_CMP_CND]);
-  rc |= run<EXP_QUARTER>(kInsts[EXP_QUARTER]);
-  if (c1 > 0) rc |= run<COMPOSITE1>(c1);
-  if (c2 > 0) rc |= run<COMPOSITE2>(c2);
+  rc |= run<INDEP_FMA>(n[INDEP_FMA]);
+  rc |= run<CHAIN1>(n[CHAIN1]);
+  rc |= run<CHAIN2>(n[CHAIN2]);
+  rc |= run<MUL_CMP_CND>(n[MUL_CMP_CND]);
+  rc |= run<EXP_QUARTER>(n[EXP_QUARTER]);
+  rc |= run<PK_FMA>(n[PK_FMA]);
+  rc |= run<PK_CHAIN>(n[PK_CHAIN]);
+  rc |= run<COMPOSITE1>(n[COMPOSITE1]);
+  rc |= run<COMPOSITE2>(n[COMPOSITE2]);
   return rc;
 }
