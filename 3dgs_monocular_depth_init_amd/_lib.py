@@ -74,6 +74,21 @@ SIGNATURES.update({
     "gsr_m3d_postprocess": [_i, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _p, _p],
     "gsr_unproject_emit": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 })
+SIGNATURES.update({
+    "gsr_dn_gemm": [_i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "gsr_dn_layernorm": [_i, _i, _p, _i, _i, _p, _p, _f, _p, _i, _p, _i, _i, _p],
+    "gsr_dn_attention": [_i, _i, _i, _p, _i, _p, _f, _p, _i, _p],
+    "gsr_dn_patch_rows": [_i, _i, _i, _i, _p, _p, _p],
+    "gsr_dn_im2col": [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
+    "gsr_dn_resize": [_i, _i, _i, _p, _i, _i, _i, _p, _i, _i, _p],
+    "gsr_dn_avgpool3s2": [_i, _i, _i, _p, _i, _p, _i, _p],
+    "gsr_dn_slice": [_i64, _i, _p, _i, _p, _i, _f, _i, _i, _p],
+    "gsr_dn_gru_gate": [_i64, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "gsr_dn_depth_expectation": [_i64, _i, _p, _i, _f, _f, _f, _p, _i, _p],
+    "gsr_dn_normal_head": [_i64, _p, _i, _p, _i, _p, _i, _p],
+    "gsr_dn_convex_upsample": [_i, _i, _i, _p, _p, _i, _f, _f, _f, _p, _p, _p, _p],
+    "gsr_dn_cvt_f32_f16": [_i64, _i, _p, _i, _p, _i, _p],
+})
 OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)
 
 

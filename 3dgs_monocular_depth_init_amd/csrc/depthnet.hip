@@ -1,0 +1,815 @@
+// depthnet.hip -- B10: the dense monocular depth network (Metric3D v2: DINOv2-reg ViT encoder +
+// RAFT-DPT decoder) on the gfx950 matrix cores, fp16 operands / fp32 accumulation.
+//
+// Architecture spec (read as text, nothing copied): /root/reference/gs_init_compare/third_party/
+// metric3d/mono/model/backbones/ViT_DINO_reg.py:755-1270 (DinoVisionTransformer; vit_small_reg
+// :1192, vit_large_reg :1227) and .../decode_heads/RAFTDepthNormalDPTDecoder5.py:736-1035, reached
+// from depth_prediction/predictors/metric3d.py:87-88 (`model.inference`).
+//
+// Building blocks (all hand-written, no BLAS / MIOpen):
+//   gemm_kernel        C = epilogue(A[M,K] * W[N,K]^T): 128x128x64 tiles, 4 waves x (2x2) tiles of
+//                      v_mfma_f32_32x32x16_f16, LDS double buffer, fused bias / GELU / ReLU /
+//                      sigmoid / tanh / layer-scale / residual epilogue. Every Linear, every 1x1
+//                      convolution (NHWC) and -- through im2col rows -- every 3x3 convolution.
+//   attention_kernel   flash-style softmax(QK^T/sqrt(d))V for head_dim 64: S^T = K Q^T on MFMA so
+//                      that a query is a LANE (softmax over keys = over the lane's registers + one
+//                      cross-half exchange), P stays in registers as the B operand of O^T += V^T P.
+//   layernorm / im2col / resize / pooling / GRU gates / softmax-expectation / convex upsampling:
+//                      HBM-bound element-wise kernels around the GEMMs.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace gsr {
+namespace dn {
+
+typedef _Float16 h16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDT = 72;   // LDS row stride in halves: 144 B = 36 dwords, so the 16 rows of a
+                          // quarter-wave's ds_read_b128 start in 16 distinct 4-bank groups
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+
+struct GemmArgs {
+  int M, N, K;
+  const h16 *A;
+  int lda;
+  const h16 *W;        // [N, K] row-major (nn.Linear / flattened conv weight), K % 64 == 0
+  const float *bias;   // [N] or null
+  const float *gamma;  // [N] or null: layer scale applied after the activation
+  const float *residual;   // [M, ldr] fp32 or null, added last (may alias out32)
+  int ldr;
+  const h16 *residual16;   // [M, ldr16] fp16 or null, added last
+  int ldr16;
+  h16 *out16;
+  int ldo16;
+  float *out32;
+  int ldo32;
+  int act;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+  if (ACT == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256, 2)
+gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) h16 sA[2][BM * LDT];
+  __shared__ __attribute__((aligned(16))) h16 sB[2][BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // staging map: chunk c = tid + 256*i, i = 0..3: row = (tid >> 3) + 32 i, 16-byte piece (tid & 7)
+  const int srow = tid >> 3, skc = (tid & 7) * 8;
+  const h16 *ga0 = p.A + (int64_t)min(m0 + srow, p.M - 1) * p.lda + skc;
+  const h16 *ga1 = p.A + (int64_t)min(m0 + srow + 32, p.M - 1) * p.lda + skc;
+  const h16 *ga2 = p.A + (int64_t)min(m0 + srow + 64, p.M - 1) * p.lda + skc;
+  const h16 *ga3 = p.A + (int64_t)min(m0 + srow + 96, p.M - 1) * p.lda + skc;
+  const h16 *gb0 = p.W + (int64_t)min(n0 + srow, p.N - 1) * p.K + skc;
+  const h16 *gb1 = p.W + (int64_t)min(n0 + srow + 32, p.N - 1) * p.K + skc;
+  const h16 *gb2 = p.W + (int64_t)min(n0 + srow + 64, p.N - 1) * p.K + skc;
+  const h16 *gb3 = p.W + (int64_t)min(n0 + srow + 96, p.N - 1) * p.K + skc;
+  const int so = srow * LDT + skc;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define DN_GLOAD(k0)                                                  \
+  ra0 = *reinterpret_cast<const uint4 *>(ga0 + (k0));                 \
+  ra1 = *reinterpret_cast<const uint4 *>(ga1 + (k0));                 \
+  ra2 = *reinterpret_cast<const uint4 *>(ga2 + (k0));                 \
+  ra3 = *reinterpret_cast<const uint4 *>(ga3 + (k0));                 \
+  rb0 = *reinterpret_cast<const uint4 *>(gb0 + (k0));                 \
+  rb1 = *reinterpret_cast<const uint4 *>(gb1 + (k0));                 \
+  rb2 = *reinterpret_cast<const uint4 *>(gb2 + (k0));                 \
+  rb3 = *reinterpret_cast<const uint4 *>(gb3 + (k0));
+#define DN_SSTORE(buf)                                                         \
+  *reinterpret_cast<uint4 *>(&sA[buf][so]) = ra0;                              \
+  *reinterpret_cast<uint4 *>(&sA[buf][so + 32 * LDT]) = ra1;                   \
+  *reinterpret_cast<uint4 *>(&sA[buf][so + 64 * LDT]) = ra2;                   \
+  *reinterpret_cast<uint4 *>(&sA[buf][so + 96 * LDT]) = ra3;                   \
+  *reinterpret_cast<uint4 *>(&sB[buf][so]) = rb0;                              \
+  *reinterpret_cast<uint4 *>(&sB[buf][so + 32 * LDT]) = rb1;                   \
+  *reinterpret_cast<uint4 *>(&sB[buf][so + 64 * LDT]) = rb2;                   \
+  *reinterpret_cast<uint4 *>(&sB[buf][so + 96 * LDT]) = rb3;
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+
+  const int nk = p.K / BK;
+  DN_GLOAD(0)
+  DN_SSTORE(0)
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      DN_GLOAD((kt + 1) * BK)
+    }
+    const h16 *a_base = &sA[buf][(wm * 64 + lr) * LDT + lh * 8];
+    const h16 *b_base = &sB[buf][(wn * 64 + lr) * LDT + lh * 8];
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      const half8 af0 = *reinterpret_cast<const half8 *>(a_base + s * 16);
+      const half8 af1 = *reinterpret_cast<const half8 *>(a_base + 32 * LDT + s * 16);
+      const half8 bf0 = *reinterpret_cast<const half8 *>(b_base + s * 16);
+      const half8 bf1 = *reinterpret_cast<const half8 *>(b_base + 32 * LDT + s * 16);
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc11, 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      if (buf == 0) {
+        DN_SSTORE(1)
+      } else {
+        DN_SSTORE(0)
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#undef DN_GLOAD
+#undef DN_SSTORE
+
+  // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
+  auto emit = [&](const f32x16 &acc, int i, int j) {
+    const int n = n0 + wn * 64 + j * 32 + lr;
+    if (n >= p.N) return;
+    const float b = p.bias ? p.bias[n] : 0.f;
+    const float g = p.gamma ? p.gamma[n] : 1.f;
+    const int mb = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (m >= p.M) continue;
+      float v = act_fn<ACT>(acc[r] + b) * g;
+      if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+      if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
+      if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
+      if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
+    }
+  };
+  emit(acc00, 0, 0);
+  emit(acc01, 0, 1);
+  emit(acc10, 1, 0);
+  emit(acc11, 1, 1);
+}
+
+// ---- LayerNorm over the last dimension: one wave per row, fp32 statistics -------------------
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(int M, int D, const TIN *__restrict__ x, int ldx, const float *__restrict__ gamma,
+                 const float *__restrict__ beta, float eps, h16 *__restrict__ out16, int ldo16,
+                 float *__restrict__ out32, int ldo32, int relu) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const TIN *xr = x + (int64_t)row * ldx;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += (float)xr[i];
+  s = wave_sum(s);
+  const float mean = s / (float)D;
+  float v = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float d = (float)xr[i] - mean;
+    v += d * d;
+  }
+  v = wave_sum(v);
+  const float rstd = rsqrtf(v / (float)D + eps);
+  for (int i = lane; i < D; i += 64) {
+    float y = ((float)xr[i] - mean) * rstd * gamma[i] + beta[i];
+    if (relu) y = fmaxf(y, 0.f);
+    if (out16) out16[(int64_t)row * ldo16 + i] = (h16)y;
+    if (out32) out32[(int64_t)row * ldo32 + i] = y;
+  }
+}
+
+// ---- V^T for the attention kernel: Vt[h][d][key], keys zero-padded to n_pad -----------------
+__global__ void __launch_bounds__(256)
+transpose_v_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, int ld,
+                   h16 *__restrict__ vt) {
+  __shared__ h16 tile[64][66];
+  const int h = blockIdx.y, t0 = blockIdx.x * 64;
+  const int D = heads * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int t = i >> 6, d = i & 63;
+    tile[t][d] = (t0 + t < n_tok) ? qkv[(int64_t)(t0 + t) * ld + 2 * D + h * 64 + d] : (h16)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int d = i >> 6, t = i & 63;
+    if (t0 + t < n_pad) vt[((int64_t)h * 64 + d) * n_pad + t0 + t] = tile[t][d];
+  }
+}
+
+// ---- attention, head_dim 64 ---------------------------------------------------------------
+// grid (ceil(n_tok / 128), heads), 4 waves; wave w owns queries q0 + 32 w .. + 31 (one per
+// lane column). Per 32-key tile: S^T = K Q^T (4 MFMA), online softmax in registers, then
+// O^T += V^T P (4 MFMA) with P taken straight from the S^T accumulator registers: after
+// v_mfma_f32_32x32x16 register e of lane-half h is key row (e&3) + 8(e>>2) + 4h, so the B
+// fragment of k-step s is registers 8s..8s+7 and element j stands for key 16s + 8(j>>2) + 4h +
+// (j&3); the V^T fragment (A operand) is read from LDS in that same key order.
+constexpr int KT = 32;        // keys per tile
+constexpr int LDK = 72;       // sK row stride (halves)
+constexpr int LDV = 40;       // sVt row stride (halves): 32 keys + 8 pad
+
+__global__ void __launch_bounds__(256)
+attention_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, int ld,
+                 const h16 *__restrict__ vt, float scale_log2e, h16 *__restrict__ out, int ldo) {
+  __shared__ __attribute__((aligned(16))) h16 sK[2][KT * LDK];
+  __shared__ __attribute__((aligned(16))) h16 sV[2][64 * LDV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int h = blockIdx.y, D = heads * 64;
+  const int q = blockIdx.x * 128 + wave * 32 + lr;
+  const int qc = min(q, n_tok - 1);
+
+  half8 qf[4];   // B operand of S^T: B[k = d][col = query]: lane (r, h) holds Q[q][16s + 8h + j]
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    qf[s] = *reinterpret_cast<const half8 *>(qkv + (int64_t)qc * ld + h * 64 + s * 16 + lh * 8);
+
+  // staging: K tile = 32 keys x 64 d = 256 pieces of 16 B; Vt tile = 64 d x 32 keys = 256 pieces
+  const int k_row = tid >> 3, k_pc = (tid & 7) * 8;
+  const int v_row = tid >> 2, v_pc = (tid & 3) * 8;
+  const h16 *gk = qkv + D + h * 64 + k_pc;
+  const h16 *gv = vt + ((int64_t)h * 64 + v_row) * n_pad + v_pc;
+  uint4 rk, rv;
+  auto gload = [&](int key0) {
+    rk = *reinterpret_cast<const uint4 *>(gk + (int64_t)min(key0 + k_row, n_tok - 1) * ld);
+    rv = *reinterpret_cast<const uint4 *>(gv + key0);
+  };
+  auto sstore = [&](int buf) {
+    *reinterpret_cast<uint4 *>(&sK[buf][k_row * LDK + k_pc]) = rk;
+    *reinterpret_cast<uint4 *>(&sV[buf][v_row * LDV + v_pc]) = rv;
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int n_tiles = (n_tok + KT - 1) / KT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    if (kt + 1 < n_tiles) gload((kt + 1) * KT);
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8 kf = *reinterpret_cast<const half8 *>(&sK[buf][lr * LDK + s * 16 + lh * 8]);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+    }
+    const int key0 = kt * KT;
+    if (key0 + KT > n_tok) {   // last tile: keys beyond the sequence take no weight
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= n_tok) st[r] = -1e30f;
+    }
+    float m_loc = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, st[r]);
+    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+    const float m_new = fmaxf(m_run, m_loc);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    float l_loc = 0.f;
+    half8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f((st[r] - m_new) * scale_log2e);
+      l_loc += pv;
+      pf[r >> 3][r & 7] = (h16)pv;
+    }
+    l_loc += __shfl_xor(l_loc, 32, 64);
+    l_run = l_run * alpha + l_loc;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // A[row = d][k = 8h + j] = Vt[d][16s + 8(j>>2) + 4h + (j&3)]: two 8-byte reads
+        const h16 *vrow = &sV[buf][(t * 32 + lr) * LDV + s * 16 + lh * 4];
+        const half4 lo = *reinterpret_cast<const half4 *>(vrow);
+        const half4 hi = *reinterpret_cast<const half4 *>(vrow + 8);
+        half8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < n_tiles) {
+      sstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  if (q < n_tok) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(int64_t)q * ldo + h * 64 + d] = (h16)(o[t][r] * inv);
+      }
+  }
+}
+
+// ---- patch / convolution rows --------------------------------------------------------------
+// Patch embedding (Conv2d k = stride = P on an NCHW fp32 image): row = patch, column
+// c*P*P + ky*P + kx (the flattening of the conv weight [D, 3, P, P]); columns >= 3*P*P are zero.
+__global__ void __launch_bounds__(256)
+patch_rows_kernel(int H, int W, int P, int K_pad, const float *__restrict__ img, h16 *__restrict__ rows) {
+  const int gw = W / P;
+  const int64_t total = (int64_t)(H / P) * gw * K_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % K_pad);
+    const int patch = (int)(i / K_pad);
+    float v = 0.f;
+    if (col < 3 * P * P) {
+      const int c = col / (P * P), rem = col - c * P * P, ky = rem / P, kx = rem - ky * P;
+      const int py = patch / gw, px = patch - py * gw;
+      v = img[((int64_t)c * H + py * P + ky) * W + px * P + kx];
+    }
+    rows[i] = (h16)v;
+  }
+}
+
+// im2col for a KSxKS convolution over an NHWC fp16 map: row = output pixel, column
+// (ky*KS + kx)*C + c; zero outside the image and in the K padding.
+__global__ void __launch_bounds__(256)
+im2col_kernel(int H, int W, int C, int ldi, int KS, int stride, int pad, int Ho, int Wo, int K_pad,
+              const h16 *__restrict__ in, h16 *__restrict__ rows, int relu) {
+  const int64_t total = (int64_t)Ho * Wo * (K_pad / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int col8 = (int)(i % (K_pad / 8)) * 8;
+    const int pix = (int)(i / (K_pad / 8));
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (h16)0;
+    if ((C & 7) == 0) {   // the 8 columns share one tap: one 16-byte read
+      if (col8 < KS * KS * C) {
+        const int tap = col8 / C, c = col8 - tap * C, ky = tap / KS, kx = tap - ky * KS;
+        const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+          v = *reinterpret_cast<const half8 *>(in + ((int64_t)iy * W + ix) * ldi + c);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = col8 + e;
+        if (col < KS * KS * C) {
+          const int tap = col / C, c = col - tap * C, ky = tap / KS, kx = tap - ky * KS;
+          const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[e] = in[((int64_t)iy * W + ix) * ldi + c];
+        }
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > (h16)0 ? v[e] : (h16)0;
+    }
+    *reinterpret_cast<half8 *>(rows + (int64_t)pix * K_pad + col8) = v;
+  }
+}
+
+// ---- element-wise pieces of the decoder (NHWC fp16 maps, `ld` = channel stride of a pixel) ----
+// out = resize(in) [+ add]; mode 0 nearest (floor(dst * scale)), 1 bilinear align_corners=True,
+// 2 bilinear align_corners=False (half-pixel centres, clamped)
+__global__ void __launch_bounds__(256)
+resize_kernel(int Hi, int Wi, int C, const h16 *__restrict__ in, int ldi, int Ho, int Wo,
+              h16 *__restrict__ out, int ldo, int mode, float sy, float sx) {
+  const int64_t total = (int64_t)Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int pix = (int)(i / C);
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    float v;
+    if (mode == 0) {
+      const int iy = min((int)floorf(oy * sy), Hi - 1), ix = min((int)floorf(ox * sx), Wi - 1);
+      v = (float)in[((int64_t)iy * Wi + ix) * ldi + c];
+    } else {
+      float fy, fx;
+      if (mode == 1) {
+        fy = oy * sy;
+        fx = ox * sx;
+      } else {
+        fy = fmaxf((oy + 0.5f) * sy - 0.5f, 0.f);
+        fx = fmaxf((ox + 0.5f) * sx - 0.5f, 0.f);
+      }
+      const int y0 = min((int)fy, Hi - 1), x0 = min((int)fx, Wi - 1);
+      const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+      const float wy = fy - (float)y0, wx = fx - (float)x0;
+      const float a = (float)in[((int64_t)y0 * Wi + x0) * ldi + c], b = (float)in[((int64_t)y0 * Wi + x1) * ldi + c];
+      const float d = (float)in[((int64_t)y1 * Wi + x0) * ldi + c], e = (float)in[((int64_t)y1 * Wi + x1) * ldi + c];
+      v = (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * d + wx * e);
+    }
+    out[(int64_t)pix * ldo + c] = (h16)v;
+  }
+}
+
+// F.avg_pool2d(x, 3, stride 2, padding 1), count_include_pad=True (divide by 9)
+__global__ void __launch_bounds__(256)
+avgpool3s2_kernel(int Hi, int Wi, int C, const h16 *__restrict__ in, int ldi, int Ho, int Wo,
+                  h16 *__restrict__ out, int ldo) {
+  const int64_t total = (int64_t)Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int pix = (int)(i / C);
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    float s = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+        if (iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) s += (float)in[((int64_t)iy * Wi + ix) * ldi + c];
+      }
+    out[(int64_t)pix * ldo + c] = (h16)(s * (1.0f / 9.0f));
+  }
+}
+
+// generic strided copy / add / scale of channel slices: out[p, co + c] = a*in[p, ci + c] (+ out)
+__global__ void __launch_bounds__(256)
+slice_kernel(int64_t P, int C, const h16 *__restrict__ in, int ldi, h16 *__restrict__ out, int ldo,
+             float a, int accumulate, int act) {
+  const int64_t total = P * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    float v = a * (float)in[pix * ldi + c];
+    if (accumulate) v += (float)out[pix * ldo + c];
+    out[pix * ldo + c] = (h16)apply_act(v, act);
+  }
+}
+
+// ConvGRU gate algebra (RAFTDepthNormalDPTDecoder5.py ConvGRU.forward):
+//   stage 0: z = sigmoid(zr[:, 0:C] + cz), r = sigmoid(zr[:, C:2C] + cr); writes z and r*h
+//   stage 1: q = tanh(qin + cq); h = (1 - z) h + z q
+__global__ void __launch_bounds__(256)
+gru_gate_kernel(int64_t P, int C, int stage, const h16 *__restrict__ zr, int ldzr,
+                const h16 *__restrict__ ctx, int ldc, h16 *__restrict__ h, int ldh,
+                h16 *__restrict__ z, int ldz, h16 *__restrict__ rh, int ldrh) {
+  const int64_t total = P * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    if (stage == 0) {
+      const float zz = 1.f / (1.f + __expf(-((float)zr[p * ldzr + c] + (float)ctx[p * ldc + c])));
+      const float rr = 1.f / (1.f + __expf(-((float)zr[p * ldzr + C + c] + (float)ctx[p * ldc + C + c])));
+      z[p * ldz + c] = (h16)zz;
+      rh[p * ldrh + c] = (h16)(rr * (float)h[p * ldh + c]);
+    } else {
+      const float qq = tanhf((float)zr[p * ldzr + c] + (float)ctx[p * ldc + 2 * C + c]);
+      const float zz = (float)z[p * ldz + c], hh = (float)h[p * ldh + c];
+      h[p * ldh + c] = (h16)((1.f - zz) * hh + zz * qq);
+    }
+  }
+}
+
+// depth head: softmax over the `bins` logits of a pixel, expectation over log-spaced depth bins,
+// clamp to [min, max], then (d - max) / regress_scale (regress_depth, decoder :806-838)
+__global__ void __launch_bounds__(256)
+depth_expectation_kernel(int64_t P, int bins, const h16 *__restrict__ logits, int ld, float log_min,
+                         float log_max, float min_val, float max_val, float regress_scale,
+                         float *__restrict__ out, int ldo) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (p >= P) return;
+  const h16 *l = logits + p * ld;
+  float m = -1e30f;
+  for (int i = lane; i < bins; i += 64) m = fmaxf(m, (float)l[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f, e = 0.f;
+  for (int i = lane; i < bins; i += 64) {
+    const float w = __expf((float)l[i] - m);
+    const float depth = __expf(log_min + (log_max - log_min) * (float)i / (float)(bins - 1));
+    s += w;
+    e += w * depth;
+  }
+  s = wave_sum(s);
+  e = wave_sum(e);
+  if (lane == 0) {
+    float d = e / s;
+    d = fminf(fmaxf(d, min_val), max_val);
+    out[p * ldo] = (d - max_val) / regress_scale;
+  }
+}
+
+// norm_normalize (decoder :252-258): xyz / (|xyz| + 1e-10), kappa = elu(k) + 1 + 0.01
+__device__ __forceinline__ void norm_normalize4(float &x, float &y, float &z, float &k) {
+  const float n = sqrtf(x * x + y * y + z * z) + 1e-10f;
+  x /= n;
+  y /= n;
+  z /= n;
+  k = (k > 0.f ? k : (__expf(k) - 1.f)) + 1.0f + 0.01f;
+}
+
+__global__ void __launch_bounds__(256)
+normal_head_kernel(int64_t P, const h16 *__restrict__ nrm, int ldn, const h16 *__restrict__ conf,
+                   int ldc, float *__restrict__ out, int ldo) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float x = (float)nrm[p * ldn], y = (float)nrm[p * ldn + 1], z = (float)nrm[p * ldn + 2];
+  float k = (float)conf[p * ldc];
+  norm_normalize4(x, y, z, k);
+  out[p * ldo] = x;
+  out[p * ldo + 1] = y;
+  out[p * ldo + 2] = z;
+  out[p * ldo + 3] = k;
+}
+
+// Convex upsampling of the 6-channel flow (upsample_flow, decoder :870-884) fused with the
+// output heads (:985-987): for low-res pixel (y, x) and sub-position (i, j) of the FxF cell,
+// weights = softmax over the 9 taps of mask[(tap*F + i)*F + j], value = sum_tap w * flow[3x3
+// neighbour, zero padded]. Writes depth = clamp(v0 * regress_scale + max), confidence = v1,
+// normal = norm_normalize(v2..5) as [1,*,H*F,W*F] planes.
+__global__ void __launch_bounds__(256)
+convex_upsample_kernel(int H, int W, int F, const float *__restrict__ flow /* [H*W,6] */,
+                       const h16 *__restrict__ mask, int ldm, float min_val, float max_val,
+                       float regress_scale, float *__restrict__ depth, float *__restrict__ conf,
+                       float *__restrict__ normal /* [4, H*F, W*F] */) {
+  const int64_t total = (int64_t)H * W * F * F;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int sub = (int)(i % (F * F));
+  const int pix = (int)(i / (F * F));
+  const int si = sub / F, sj = sub - si * F;
+  const int y = pix / W, x = pix - y * W;
+  float w[9], m = -1e30f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    w[t] = (float)mask[(int64_t)pix * ldm + (t * F + si) * F + sj];
+    m = fmaxf(m, w[t]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    w[t] = __expf(w[t] - m);
+    s += w[t];
+  }
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const float ww = w[t] / s;
+    const float *f = flow + ((int64_t)yy * W + xx) * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] += ww * f[c];
+  }
+  const int HF = H * F, WF = W * F;
+  const int64_t o = (int64_t)(y * F + si) * WF + x * F + sj;
+  float d = v[0] * regress_scale + max_val;
+  depth[o] = fminf(fmaxf(d, min_val), max_val);
+  conf[o] = v[1];
+  norm_normalize4(v[2], v[3], v[4], v[5]);
+  const int64_t plane = (int64_t)HF * WF;
+  normal[o] = v[2];
+  normal[plane + o] = v[3];
+  normal[2 * plane + o] = v[4];
+  normal[3 * plane + o] = v[5];
+}
+
+// fp32 <-> fp16 row conversions with strides (token rows, flow maps)
+__global__ void __launch_bounds__(256)
+cvt_kernel(int64_t P, int C, const float *__restrict__ in, int ldi, h16 *__restrict__ out, int ldo) {
+  const int64_t total = P * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    out[p * ldo + c] = (h16)in[p * ldi + c];
+  }
+}
+
+static inline unsigned grid_for(int64_t total) {
+  const int64_t b = ceil_div64(total, 256);
+  return (unsigned)(b < 65536 ? b : 65536);
+}
+
+}  // namespace dn
+}  // namespace gsr
+
+using namespace gsr::dn;
+
+extern "C" int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W,
+                           const float *bias, int act, const float *gamma, const float *residual,
+                           int ldr, const void *residual16, int ldr16, void *out16, int ldo16,
+                           float *out32, int ldo32, void *stream) {
+  GSR_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % gsr::dn::BK == 0, "dn_gemm: bad sizes M=%d N=%d K=%d (K %% 64)", M, N, K);
+  if (M == 0 || N == 0) return GSR_OK;
+  GSR_REQUIRE(A && W && (out16 || out32), "dn_gemm: null pointer");
+  GSR_REQUIRE(lda >= K && (lda % 8) == 0, "dn_gemm: lda %d (>= K, multiple of 8 halves)", lda);
+  GSR_REQUIRE(act >= 0 && act <= 4, "dn_gemm: act %d", act);
+  GemmArgs p;
+  p.M = M; p.N = N; p.K = K;
+  p.A = (const h16 *)A; p.lda = lda; p.W = (const h16 *)W;
+  p.bias = bias; p.gamma = gamma; p.residual = residual; p.ldr = ldr;
+  p.residual16 = (const h16 *)residual16; p.ldr16 = ldr16;
+  p.out16 = (h16 *)out16; p.ldo16 = ldo16; p.out32 = out32; p.ldo32 = ldo32;
+  p.act = act;
+  dim3 grid((unsigned)gsr::ceil_div(N, gsr::dn::BN), (unsigned)gsr::ceil_div(M, gsr::dn::BM));
+  switch (act) {
+    case ACT_GELU: hipLaunchKernelGGL(gemm_kernel<ACT_GELU>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case ACT_RELU: hipLaunchKernelGGL(gemm_kernel<ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case ACT_SIGMOID: hipLaunchKernelGGL(gemm_kernel<ACT_SIGMOID>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case ACT_TANH: hipLaunchKernelGGL(gemm_kernel<ACT_TANH>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(gemm_kernel<ACT_NONE>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+  }
+  GSR_CHECK_LAUNCH("dn_gemm");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,
+                                const float *beta, float eps, void *out16, int ldo16, float *out32,
+                                int ldo32, int relu, void *stream) {
+  GSR_REQUIRE(M >= 0 && D > 0, "dn_layernorm: bad sizes");
+  if (M == 0) return GSR_OK;
+  GSR_REQUIRE(x && gamma && beta && (out16 || out32), "dn_layernorm: null pointer");
+  dim3 grid((unsigned)gsr::ceil_div(M, 4));
+  if (x_is_f16)
+    hipLaunchKernelGGL(layernorm_kernel<h16>, grid, dim3(256), 0, (hipStream_t)stream, M, D,
+                       (const h16 *)x, ldx, gamma, beta, eps, (h16 *)out16, ldo16, out32, ldo32, relu);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, D,
+                       (const float *)x, ldx, gamma, beta, eps, (h16 *)out16, ldo16, out32, ldo32, relu);
+  GSR_CHECK_LAUNCH("dn_layernorm");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_attention(int n_tok, int n_pad, int heads, const void *qkv, int ld, void *vt_scratch,
+                                float scale, void *out, int ldo, void *stream) {
+  GSR_REQUIRE(n_tok > 0 && heads > 0 && n_pad >= n_tok && n_pad % 32 == 0,
+              "dn_attention: bad sizes n_tok=%d n_pad=%d (multiple of 32)", n_tok, n_pad);
+  GSR_REQUIRE(qkv && vt_scratch && out && ld >= 3 * heads * 64 && (ld % 8) == 0, "dn_attention: bad arguments");
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)gsr::ceil_div(n_pad, 64), (unsigned)heads),
+                     dim3(256), 0, (hipStream_t)stream, n_tok, n_pad, heads, (const h16 *)qkv, ld,
+                     (h16 *)vt_scratch);
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)gsr::ceil_div(n_tok, 128), (unsigned)heads),
+                     dim3(256), 0, (hipStream_t)stream, n_tok, n_pad, heads, (const h16 *)qkv, ld,
+                     (const h16 *)vt_scratch, scale * 1.4426950408889634f, (h16 *)out, ldo);
+  GSR_CHECK_LAUNCH("dn_attention");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_patch_rows(int H, int W, int P, int K_pad, const float *img, void *rows, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && P > 0 && H % P == 0 && W % P == 0 && K_pad >= 3 * P * P, "dn_patch_rows: bad sizes");
+  GSR_REQUIRE(img && rows, "dn_patch_rows: null pointer");
+  const int64_t total = (int64_t)(H / P) * (W / P) * K_pad;
+  hipLaunchKernelGGL(patch_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, H, W, P,
+                     K_pad, img, (h16 *)rows);
+  GSR_CHECK_LAUNCH("dn_patch_rows");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_im2col(int H, int W, int C, int ldi, int KS, int stride, int pad, int Ho, int Wo,
+                             int K_pad, const void *in, void *rows, int relu, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && C > 0 && KS > 0 && stride > 0 && Ho > 0 && Wo > 0 &&
+                  K_pad >= KS * KS * C && K_pad % 8 == 0,
+              "dn_im2col: bad sizes");
+  GSR_REQUIRE(in && rows, "dn_im2col: null pointer");
+  GSR_REQUIRE((C & 7) != 0 || (ldi & 7) == 0, "dn_im2col: ldi must be a multiple of 8 for vector reads");
+  const int64_t total = (int64_t)Ho * Wo * (K_pad / 8);
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, H, W, C, ldi,
+                     KS, stride, pad, Ho, Wo, K_pad, (const h16 *)in, (h16 *)rows, relu);
+  GSR_CHECK_LAUNCH("dn_im2col");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_resize(int Hi, int Wi, int C, const void *in, int ldi, int Ho, int Wo, void *out,
+                             int ldo, int mode, void *stream) {
+  GSR_REQUIRE(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && mode >= 0 && mode <= 2, "dn_resize: bad sizes");
+  GSR_REQUIRE(in && out, "dn_resize: null pointer");
+  float sy, sx;
+  if (mode == 1) {
+    sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  } else {
+    sy = (float)Hi / (float)Ho;
+    sx = (float)Wi / (float)Wo;
+  }
+  hipLaunchKernelGGL(resize_kernel, dim3(grid_for((int64_t)Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream,
+                     Hi, Wi, C, (const h16 *)in, ldi, Ho, Wo, (h16 *)out, ldo, mode, sy, sx);
+  GSR_CHECK_LAUNCH("dn_resize");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_avgpool3s2(int Hi, int Wi, int C, const void *in, int ldi, void *out, int ldo,
+                                 void *stream) {
+  GSR_REQUIRE(Hi > 0 && Wi > 0 && C > 0 && in && out, "dn_avgpool3s2: bad arguments");
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(avgpool3s2_kernel, dim3(grid_for((int64_t)Ho * Wo * C)), dim3(256), 0,
+                     (hipStream_t)stream, Hi, Wi, C, (const h16 *)in, ldi, Ho, Wo, (h16 *)out, ldo);
+  GSR_CHECK_LAUNCH("dn_avgpool3s2");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_slice(int64_t P, int C, const void *in, int ldi, void *out, int ldo, float a,
+                            int accumulate, int act, void *stream) {
+  GSR_REQUIRE(P >= 0 && C > 0 && act >= 0 && act <= 4, "dn_slice: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(in && out, "dn_slice: null pointer");
+  hipLaunchKernelGGL(slice_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, P, C,
+                     (const h16 *)in, ldi, (h16 *)out, ldo, a, accumulate, act);
+  GSR_CHECK_LAUNCH("dn_slice");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_gru_gate(int64_t P, int C, int stage, const void *zr, int ldzr, const void *ctx,
+                               int ldc, void *h, int ldh, void *z, int ldz, void *rh, int ldrh,
+                               void *stream) {
+  GSR_REQUIRE(P >= 0 && C > 0 && (stage == 0 || stage == 1), "dn_gru_gate: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(zr && ctx && h && z && (stage == 1 || rh), "dn_gru_gate: null pointer");
+  hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, P, C, stage,
+                     (const h16 *)zr, ldzr, (const h16 *)ctx, ldc, (h16 *)h, ldh, (h16 *)z, ldz,
+                     (h16 *)rh, ldrh);
+  GSR_CHECK_LAUNCH("dn_gru_gate");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_depth_expectation(int64_t P, int bins, const void *logits, int ld, float min_val,
+                                        float max_val, float regress_scale, float *out, int ldo,
+                                        void *stream) {
+  GSR_REQUIRE(P >= 0 && bins > 1 && min_val > 0.f && max_val > min_val, "dn_depth_expectation: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(logits && out, "dn_depth_expectation: null pointer");
+  hipLaunchKernelGGL(depth_expectation_kernel, dim3((unsigned)gsr::ceil_div64(P, 4)), dim3(256), 0,
+                     (hipStream_t)stream, P, bins, (const h16 *)logits, ld, logf(min_val), logf(max_val),
+                     min_val, max_val, regress_scale, out, ldo);
+  GSR_CHECK_LAUNCH("dn_depth_expectation");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_normal_head(int64_t P, const void *nrm, int ldn, const void *conf, int ldc,
+                                  float *out, int ldo, void *stream) {
+  GSR_REQUIRE(P >= 0, "dn_normal_head: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(nrm && conf && out, "dn_normal_head: null pointer");
+  hipLaunchKernelGGL(normal_head_kernel, dim3((unsigned)gsr::ceil_div64(P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, P, (const h16 *)nrm, ldn, (const h16 *)conf, ldc, out, ldo);
+  GSR_CHECK_LAUNCH("dn_normal_head");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_convex_upsample(int H, int W, int F, const float *flow, const void *mask, int ldm,
+                                      float min_val, float max_val, float regress_scale, float *depth,
+                                      float *conf, float *normal, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && F > 0 && ldm >= 9 * F * F, "dn_convex_upsample: bad sizes");
+  GSR_REQUIRE(flow && mask && depth && conf && normal, "dn_convex_upsample: null pointer");
+  const int64_t total = (int64_t)H * W * F * F;
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)gsr::ceil_div64(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, H, W, F, flow, (const h16 *)mask, ldm, min_val, max_val,
+                     regress_scale, depth, conf, normal);
+  GSR_CHECK_LAUNCH("dn_convex_upsample");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_cvt_f32_f16(int64_t P, int C, const float *in, int ldi, void *out, int ldo,
+                                  void *stream) {
+  GSR_REQUIRE(P >= 0 && C > 0, "dn_cvt: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(in && out, "dn_cvt: null pointer");
+  hipLaunchKernelGGL(cvt_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, P, C, in, ldi,
+                     (h16 *)out, ldo);
+  GSR_CHECK_LAUNCH("dn_cvt");
+  return GSR_OK;
+}

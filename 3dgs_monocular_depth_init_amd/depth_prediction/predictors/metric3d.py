@@ -54,11 +54,26 @@ def to_og_size(t: torch.Tensor, pad_info, size, scale: float = 1.0, clamp=None) 
 
 
 class Metric3d(DepthPredictor):
-    def __init__(self, config, device: str, model=None, backbone: str = "vits"):
+    def __init__(self, config, device: str, model=None, backbone: str = None, weights=None):
+        """`Metric3d(config, device)` as in the reference (metric3d.py:19-33). The network is
+        `metric3d_net.Metric3DNet` (MFMA fp16) built from a local state dict: `weights=` (a path
+        or a dict) or $METRIC3D_WEIGHTS -- the reference's torch.hub download is unavailable
+        offline, and nothing is fetched silently. `model=` injects any object with `.inference`."""
+        import os
+        if backbone is None:
+            b = getattr(getattr(getattr(config, "mdi", None), "metric3d", None), "backbone", "vits")
+            backbone = getattr(b, "value", b)
         if model is None:
-            raise RuntimeError(
-                "Metric3d needs a depth network: the reference fetches it with torch.hub "
-                "(metric3d.py:27-31), which is unavailable offline; pass model=<network>")
+            weights = weights if weights is not None else os.environ.get("METRIC3D_WEIGHTS")
+            if weights is None:
+                raise RuntimeError(
+                    "Metric3d needs network weights: the reference fetches them with torch.hub "
+                    "(metric3d.py:27-31), which is unavailable offline; pass weights=<state dict or "
+                    "path>, set METRIC3D_WEIGHTS, or pass model=<network>")
+            from .metric3d_net import Metric3DNet
+            if not isinstance(weights, dict):
+                weights = torch.load(weights, map_location="cpu", weights_only=True)
+            model = Metric3DNet(weights, backbone=backbone, device=device, input_size=INPUT_SIZE)
         self.__name = f"Metric3d_{backbone}"
         self.__model = model
         self.device = device

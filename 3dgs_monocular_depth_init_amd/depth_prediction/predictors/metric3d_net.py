@@ -1,0 +1,448 @@
+"""The Metric3D v2 network on the gfx950 matrix cores.
+
+Stands where the reference has `torch.hub.load("yvanyin/metric3d", ...)`
+(/root/reference/gs_init_compare/depth_prediction/predictors/metric3d.py:27-31) and is called
+the same way: `net.inference({"input": rgb [1,3,616,1064]}) -> (depth [1,1,H,W],
+confidence [1,1,H,W], {"prediction_normal": [1,4,H,W]})` (metric3d.py:87-88).
+
+Architecture (read from the reference's vendored source as a spec):
+  encoder  third_party/metric3d/mono/model/backbones/ViT_DINO_reg.py:755-1270
+           (DinoVisionTransformer: patch 14, cls + 4 register tokens, pre-norm blocks with
+           LayerScale, final LayerNorm; the four "features" it returns are that one tensor)
+  decoder  third_party/metric3d/mono/model/decode_heads/RAFTDepthNormalDPTDecoder5.py:736-1035
+           (token read-out, DPT fusion, depth-bin / normal heads, 3-level ConvGRU refinement,
+           convex upsampling)
+Weights are taken from a state dict with the reference's own parameter names (prefixes
+`encoder.` / `decoder.`), so a real checkpoint loads unchanged; none is available offline, the
+tests use deterministic random weights.
+
+Everything heavy runs in csrc/depthnet.hip through the C ABI: every Linear / convolution is the
+fp16 MFMA GEMM `gsr_dn_gemm` (3x3 convolutions through `gsr_dn_im2col` rows), attention is
+`gsr_dn_attention`; torch allocates buffers and, once at construction, re-lays the weights
+(flatten / transpose / zero-pad K to 64, fp16) and interpolates the position embedding.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from ..._lib import call, load, ptr
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+RESIZE_NEAREST, RESIZE_BILINEAR_AC, RESIZE_BILINEAR = 0, 1, 2
+
+CONFIGS = {
+    # metric3d_configs: backbones/dino_vit_*_reg.py + encoder_decoder/dino_vit_*_reg.dpt_raft.py +
+    # HourglassDecoder/vit.raft5.{small,large}.py (iters)
+    "vits": dict(embed_dim=384, depth=12, heads=6, feature_channels=[96, 192, 384, 768],
+                 decoder_channels=[48, 96, 192, 384, 384], hidden=[48, 48, 48, 48], iters=4),
+    "vitl": dict(embed_dim=1024, depth=24, heads=16, feature_channels=[256, 512, 1024, 1024],
+                 decoder_channels=[128, 256, 512, 1024, 1024], hidden=[128, 128, 128, 128], iters=8),
+}
+PATCH = 14
+N_REG = 4
+MIN_VAL, MAX_VAL, REGRESS_SCALE = 0.1, 200.0, 100.0     # depth_normalize, decoder :746-748
+N_BINS = 256                                             # num_depth_regressor_anchor, decoder :762
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class _Lin:
+    """One GEMM operand set: W fp16 [N, K_pad], bias fp32 [N] (or None)."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device):
+        n, k = w.shape
+        kp = _ceil(k, 64)
+        wp = torch.zeros(n, kp, dtype=torch.float16, device=device)
+        wp[:, :k] = w.to(device=device, dtype=torch.float16)
+        self.w, self.n, self.k, self.kp = wp, n, k, kp
+        self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
+
+
+def _conv_lin(w: torch.Tensor, b, device) -> _Lin:
+    """Conv2d weight [Cout, Cin, kh, kw] -> rows in im2col column order (ky*kw + kx)*Cin + c."""
+    co = w.shape[0]
+    return _Lin(w.permute(0, 2, 3, 1).reshape(co, -1), b, device)
+
+
+class Map:
+    """NHWC fp16 feature map: tensor [H*W, ld] of which the first C channels are used."""
+
+    def __init__(self, H, W, C, device, ld=None, t=None):
+        self.H, self.W, self.C = H, W, C
+        self.ld = ld if ld is not None else _ceil(C, 8)
+        self.t = t if t is not None else torch.zeros(H * W, self.ld, dtype=torch.float16, device=device)
+
+    @property
+    def P(self):
+        return self.H * self.W
+
+    def chan(self, c0, C):
+        """View of channels [c0, c0+C) (same rows, same ld)."""
+        return Map(self.H, self.W, C, None, ld=self.ld, t=self.t[:, c0:])
+
+
+class Metric3DNet:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], backbone: str = "vits", device="cuda",
+                 input_size: Tuple[int, int] = (616, 1064), config: Optional[dict] = None):
+        load()
+        cfg = dict(CONFIGS[backbone]) if config is None else dict(config)
+        self.cfg, self.dev = cfg, torch.device(device)
+        self.H, self.W = input_size
+        assert self.H % PATCH == 0 and self.W % PATCH == 0, "input size must be a multiple of 14"
+        self.gh, self.gw = self.H // PATCH, self.W // PATCH
+        self.D, self.heads, self.depth = cfg["embed_dim"], cfg["heads"], cfg["depth"]
+        assert self.D == self.heads * 64, "head_dim 64 (all Metric3D ViTs)"
+        self.n_tok = 1 + N_REG + self.gh * self.gw
+        sd = {k[len("depth_model."):] if k.startswith("depth_model.") else k: v for k, v in state_dict.items()}
+        self._prep_encoder({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+        self._prep_decoder({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
+        self._scratch: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ weights
+    def _prep_encoder(self, sd):
+        dev, D = self.dev, self.D
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        self.patch = _Lin(sd["patch_embed.proj.weight"].reshape(D, -1), sd["patch_embed.proj.bias"], dev)
+        # interpolate_pos_encoding (ViT_DINO_reg.py:901-929): bicubic resize of the 37x37 grid by
+        # scale factors (gh + 0.1) / 37, (gw + 0.1) / 37 -- done once here (fixed input size)
+        pos = sd["pos_embed"].float()
+        n = pos.shape[1] - 1
+        s = int(math.sqrt(n))
+        grid = pos[:, 1:].reshape(1, s, s, D).permute(0, 3, 1, 2)
+        if not (self.gh * self.gw == n and self.H == self.W):
+            grid = F.interpolate(grid, scale_factor=((self.gh + 0.1) / s, (self.gw + 0.1) / s), mode="bicubic",
+                                 antialias=False)
+        assert grid.shape[-2:] == (self.gh, self.gw)
+        self.pos_patch = f32(grid.permute(0, 2, 3, 1).reshape(-1, D))                 # [gh*gw, D]
+        head = torch.cat([sd["cls_token"].float()[0] + pos[:, 0], sd["register_tokens"].float()[0]], 0)
+        self.tok_head = f32(head)                                                      # [5, D] constant rows
+        self.blocks = []
+        for i in range(self.depth):
+            p = f"blocks.0.{i}." if f"blocks.0.{i}.norm1.weight" in sd else f"blocks.{i}."
+            self.blocks.append(dict(
+                n1w=f32(sd[p + "norm1.weight"]), n1b=f32(sd[p + "norm1.bias"]),
+                qkv=_Lin(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], dev),
+                proj=_Lin(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], dev),
+                ls1=f32(sd[p + "ls1.gamma"]),
+                n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
+                fc1=_Lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dev),
+                fc2=_Lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dev),
+                ls2=f32(sd[p + "ls2.gamma"])))
+        self.norm_w, self.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
+
+    def _prep_decoder(self, sd):
+        dev = self.dev
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        conv = lambda k: _conv_lin(sd[k + ".weight"], sd.get(k + ".bias"), dev)
+        lin = lambda k: _Lin(sd[k + ".weight"], sd.get(k + ".bias"), dev)
+        self.read = []
+        for i in range(4):
+            p = f"token2feature.read_{i}.readoper."
+            self.read.append(dict(patch=lin(p + "project_patch"), learn=lin(p + "project_learn")))
+        # read_1.sample: ConvTranspose2d(k = stride = 2): out[2y+i, 2x+j, co] = sum_ci in[y,x,ci] W[ci,co,i,j]
+        w = sd["token2feature.read_1.sample.weight"]                                  # [Cin, Cout, 2, 2]
+        self.up1 = _Lin(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]),
+                        sd["token2feature.read_1.sample.bias"].repeat(4), dev)         # N = (i, j, co)
+        self.up1_cout = w.shape[1]
+        self.read0_conv = conv("token2feature.read_0.sample.0")
+        self.fuse = {}
+        for name, has_branch in (("upconv_3", False), ("upconv_2", True), ("upconv_1", True)):
+            p = f"decoder_mono.{name}."
+            blk = dict(t1=conv(p + "way_trunk.conv1"), t2=conv(p + "way_trunk.conv2"), out=conv(p + "out_conv"))
+            if has_branch:
+                blk.update(b1=conv(p + "way_branch.conv1"), b2=conv(p + "way_branch.conv2"))
+            self.fuse[name] = blk
+        self.dreg = [conv("depth_regressor.0"), conv("depth_regressor.2")]
+        self.npred = [conv(f"normal_predictor.{i}") for i in (0, 2, 4, 6)]
+        self.ctx = {}
+        for lvl in ("04", "08", "16"):
+            heads = []
+            for h in (0, 1):
+                p = f"context_feature_encoder.outputs{lvl}.{h}."
+                rb = dict(c1=conv(p + "0.conv1"), c2=conv(p + "0.conv2"), last=conv(p + "1"))
+                for n in ("norm1", "norm2"):
+                    rb[n] = (f32(sd[p + f"0.{n}.weight"]), f32(sd[p + f"0.{n}.bias"]))
+                if p + "0.downsample.0.weight" in sd:
+                    rb["ds"] = conv(p + "0.downsample.0")
+                    rb["norm3"] = (f32(sd[p + "0.norm3.weight"]), f32(sd[p + "0.norm3.bias"]))
+                heads.append(rb)
+            self.ctx[lvl] = heads
+        self.zqr = [conv(f"context_zqr_convs.{i}") for i in range(3)]
+        self.gru = {}
+        for g in ("gru08", "gru16", "gru32"):
+            p = f"update_block.{g}."
+            wz, wr = sd[p + "convz.weight"], sd[p + "convr.weight"]
+            self.gru[g] = dict(
+                zr=_conv_lin(torch.cat([wz, wr], 0), torch.cat([sd[p + "convz.bias"], sd[p + "convr.bias"]]), dev),
+                q=conv(p + "convq"), C=wz.shape[0], Cin=wz.shape[1])
+        p = "update_block.flow_head."
+        self.fh1 = _conv_lin(torch.cat([sd[p + "conv1d.weight"], sd[p + "conv1n.weight"]], 0),
+                             torch.cat([sd[p + "conv1d.bias"], sd[p + "conv1n.bias"]]), dev)
+        self.fh2d, self.fh2n = conv(p + "conv2d"), conv(p + "conv2n")
+        self.mask1, self.mask2 = conv("update_block.mask.0"), conv("update_block.mask.2")
+
+    # ------------------------------------------------------------------ primitives
+    def _buf(self, key, shape, dtype=torch.float16, zero=False):
+        t = self._scratch.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.zeros(*shape, dtype=dtype, device=self.dev)
+            self._scratch[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def gemm(self, M, lin: _Lin, A, lda, act=ACT_NONE, gamma=None, residual=None, ldr=0, residual16=None,
+             ldr16=0, out16=None, ldo16=0, out32=None, ldo32=0):
+        call("gsr_dn_gemm", M, lin.n, lin.kp, ptr(A), lda, ptr(lin.w), ptr(lin.b), act, ptr(gamma),
+             ptr(residual), ldr, ptr(residual16), ldr16, ptr(out16), ldo16, ptr(out32), ldo32, _st())
+
+    def conv(self, x: Map, lin: _Lin, ks: int, out: Map, act=ACT_NONE, relu_in=False, stride=1,
+             residual: Optional[Map] = None):
+        """out[:, :N] = act(conv_ks(x) + b) (+ residual). 1x1 convolutions read x directly."""
+        pad = ks // 2
+        Ho, Wo = (x.H + 2 * pad - ks) // stride + 1, (x.W + 2 * pad - ks) // stride + 1
+        assert (Ho, Wo) == (out.H, out.W) and lin.k == ks * ks * x.C, (lin.k, ks, x.C)
+        if ks == 1 and not relu_in and x.ld >= lin.kp and x.C == lin.k and lin.kp == lin.k:
+            A, lda = x.t, x.ld
+        else:
+            rows = self._buf(f"im2col{Ho * Wo}x{lin.kp}", (Ho * Wo, lin.kp))
+            call("gsr_dn_im2col", x.H, x.W, x.C, x.ld, ks, stride, pad, Ho, Wo, lin.kp, ptr(x.t), ptr(rows),
+                 int(relu_in), _st())
+            A, lda = rows, lin.kp
+        self.gemm(Ho * Wo, lin, A, lda, act=act, residual16=None if residual is None else residual.t,
+                  ldr16=0 if residual is None else residual.ld, out16=out.t, ldo16=out.ld)
+        return out
+
+    def resize(self, x: Map, Ho, Wo, mode, out: Optional[Map] = None) -> Map:
+        out = out if out is not None else Map(Ho, Wo, x.C, self.dev)
+        call("gsr_dn_resize", x.H, x.W, x.C, ptr(x.t), x.ld, Ho, Wo, ptr(out.t), out.ld, mode, _st())
+        return out
+
+    def copy(self, src: Map, dst: Map, a=1.0, accumulate=False, act=ACT_NONE):
+        assert src.P == dst.P
+        call("gsr_dn_slice", src.P, src.C, ptr(src.t), src.ld, ptr(dst.t), dst.ld, float(a), int(accumulate),
+             act, _st())
+
+    def layernorm2d(self, x: Map, wb, relu=False):
+        call("gsr_dn_layernorm", x.P, x.C, ptr(x.t), x.ld, 1, ptr(wb[0]), ptr(wb[1]), 1e-5, ptr(x.t), x.ld,
+             None, 0, int(relu), _st())
+        return x
+
+    # ------------------------------------------------------------------ encoder
+    @torch.no_grad()
+    def encode(self, img: torch.Tensor) -> torch.Tensor:
+        """img fp32 [1,3,H,W] -> final-norm tokens fp16 [n_tok, D] (forward_features, :962-1004)."""
+        D, n_tok, npatch = self.D, self.n_tok, self.gh * self.gw
+        img = img.to(device=self.dev, dtype=torch.float32).contiguous()
+        assert img.shape == (1, 3, self.H, self.W), tuple(img.shape)
+        rows = self._buf("patch_rows", (npatch, self.patch.kp))
+        call("gsr_dn_patch_rows", self.H, self.W, PATCH, self.patch.kp, ptr(img), ptr(rows), _st())
+        x = self._buf("x", (n_tok, D), torch.float32)                       # residual stream, fp32
+        x[:1 + N_REG].copy_(self.tok_head)
+        xp = x[1 + N_REG:]
+        self.gemm(npatch, self.patch, rows, self.patch.kp, residual=self.pos_patch, ldr=D, out32=xp, ldo32=D)
+        xn = self._buf("xn", (n_tok, D))
+        qkv = self._buf("qkv", (n_tok, 3 * D))
+        att = self._buf("att", (n_tok, D))
+        hid = self._buf("hid", (n_tok, 4 * D))
+        n_pad = _ceil(n_tok, 64)
+        vt = self._buf("vt", (self.heads * 64 * n_pad,))
+        scale = 64 ** -0.5
+        for b in self.blocks:
+            call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n1w"]), ptr(b["n1b"]), 1e-6, ptr(xn), D,
+                 None, 0, 0, _st())
+            self.gemm(n_tok, b["qkv"], xn, D, out16=qkv, ldo16=3 * D)
+            call("gsr_dn_attention", n_tok, n_pad, self.heads, ptr(qkv), 3 * D, ptr(vt), scale, ptr(att), D, _st())
+            self.gemm(n_tok, b["proj"], att, D, gamma=b["ls1"], residual=x, ldr=D, out32=x, ldo32=D)
+            call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n2w"]), ptr(b["n2b"]), 1e-6, ptr(xn), D,
+                 None, 0, 0, _st())
+            self.gemm(n_tok, b["fc1"], xn, D, act=ACT_GELU, out16=hid, ldo16=4 * D)
+            self.gemm(n_tok, b["fc2"], hid, 4 * D, gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
+        tokens = torch.empty(n_tok, D, dtype=torch.float16, device=self.dev)
+        call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(self.norm_w), ptr(self.norm_b), 1e-6, ptr(tokens), D,
+             None, 0, 0, _st())
+        return tokens
+
+    # ------------------------------------------------------------------ decoder pieces
+    def _readout(self, tokens, i) -> Map:
+        """Readout (decoder :590-611): GELU(project_patch(patch tokens) + project_learn(cls + regs))."""
+        D, gh, gw = self.D, self.gh, self.gw
+        r = self.read[i]
+        learn = tokens[:1 + N_REG].reshape(1, (1 + N_REG) * D)
+        bias = torch.empty(1, D, dtype=torch.float32, device=self.dev)
+        self.gemm(1, r["learn"], learn, learn.shape[1], residual=r["patch"].b.view(1, D), ldr=D, out32=bias, ldo32=D)
+        out = Map(gh, gw, D, self.dev)
+        lin = r["patch"]
+        call("gsr_dn_gemm", gh * gw, lin.n, lin.kp, ptr(tokens[1 + N_REG:]), D, ptr(lin.w), ptr(bias), ACT_GELU,
+             None, None, 0, None, 0, ptr(out.t), out.ld, None, 0, _st())
+        return out
+
+    def _conv_block(self, x: Map, c1, c2) -> Map:
+        """ConvBlock (decoder :520-548): x + conv2(relu(conv1(relu(x))))."""
+        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev), relu_in=True)
+        return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev), relu_in=True, residual=x)
+
+    def _fuse(self, name, x1: Map, x2: Optional[Map], size) -> Map:
+        """FuseBlock (decoder :550-588). The 1x1 out_conv commutes with the bilinear upsampling
+        (interpolation weights sum to one), so it runs BEFORE it, on 1/4 or 4/49 of the pixels."""
+        f = self.fuse[name]
+        if x2 is not None:
+            b = self._conv_block(x2, f["b1"], f["b2"])
+            self.copy(x1, b, accumulate=True)                         # x1 + way_branch(x2)
+            x1 = b
+        t = self._conv_block(x1, f["t1"], f["t2"])
+        o = self.conv(t, f["out"], 1, Map(t.H, t.W, f["out"].n, self.dev))
+        if size is not None:
+            o = self.resize(o, size[0], size[1], RESIZE_BILINEAR_AC)
+        return o
+
+    def _residual_block(self, x: Map, rb) -> Map:
+        """ResidualBlock with LayerNorm2d + the trailing 3x3 conv (ContextFeatureEncoder, :412-517)."""
+        C = rb["c1"].n
+        y = self.conv(x, rb["c1"], 3, Map(x.H, x.W, C, self.dev))
+        self.layernorm2d(y, rb["norm1"], relu=True)
+        y = self.conv(y, rb["c2"], 3, Map(x.H, x.W, C, self.dev))
+        self.layernorm2d(y, rb["norm2"], relu=True)
+        if "ds" in rb:
+            xs = self.conv(x, rb["ds"], 1, Map(x.H, x.W, C, self.dev))
+            self.layernorm2d(xs, rb["norm3"])
+        else:
+            xs = x
+        self.copy(xs, y, accumulate=True, act=ACT_RELU)              # relu(x + y)
+        return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev))
+
+    def _gru(self, g, h: Map, ctx: Map, xs: List[Map]):
+        """ConvGRU.forward (decoder :318-330); h is updated in place."""
+        G = self.gru[g]
+        C = G["C"]
+        Cin = G["Cin"]
+        hx = Map(h.H, h.W, Cin, self.dev)
+        self.copy(h, hx.chan(0, C))
+        c0 = C
+        for x in xs:
+            self.copy(x, hx.chan(c0, x.C))
+            c0 += x.C
+        assert c0 == Cin, (g, c0, Cin)
+        zr = self.conv(hx, G["zr"], 3, Map(h.H, h.W, 2 * C, self.dev))
+        z = Map(h.H, h.W, C, self.dev)
+        call("gsr_dn_gru_gate", h.P, C, 0, ptr(zr.t), zr.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
+             ptr(hx.t), hx.ld, _st())                                # r*h overwrites the h slot of hx
+        q = self.conv(hx, G["q"], 3, Map(h.H, h.W, C, self.dev))
+        call("gsr_dn_gru_gate", h.P, C, 1, ptr(q.t), q.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
+             None, 0, _st())
+
+    def _pool2x(self, x: Map) -> Map:
+        out = Map((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C, self.dev)
+        call("gsr_dn_avgpool3s2", x.H, x.W, x.C, ptr(x.t), x.ld, ptr(out.t), out.ld, _st())
+        return out
+
+    # ------------------------------------------------------------------ decoder
+    @torch.no_grad()
+    def decode(self, tokens: torch.Tensor, return_intermediates: bool = False):
+        dev, gh, gw, D = self.dev, self.gh, self.gw, self.D
+        cfg = self.cfg
+        H4, W4 = int(gh * 3.5), int(gw * 3.5)            # 1/4 resolution (nearest x3.5, decoder :652)
+        H7, W7 = 2 * gh, 2 * gw                           # 1/7
+        # token2feature (EncoderFeature.forward :676-681)
+        x = self._readout(tokens, 3)                                          # 1/14, D
+        x2 = self._readout(tokens, 2)                                         # 1/14, D
+        r1 = self._readout(tokens, 1)
+        co = self.up1_cout
+        up = Map(gh, gw, 4 * co, dev)
+        self.gemm(gh * gw, self.up1, r1.t, r1.ld, out16=up.t, ldo16=up.ld)
+        x1 = Map(H7, W7, co, dev)                                             # depth-to-space of (i, j, co)
+        x1.t.view(gh, 2, gw, 2, x1.ld)[..., :co].copy_(
+            up.t[:, :4 * co].reshape(gh, gw, 2, 2, co).permute(0, 2, 1, 3, 4))
+        r0 = self._readout(tokens, 0)
+        # the 1x1 conv commutes with the nearest upsampling: convolve at 1/14, then replicate
+        x0s = self.conv(r0, self.read0_conv, 1, Map(gh, gw, self.read0_conv.n, dev))
+        x0 = self.resize(x0s, H4, W4, RESIZE_NEAREST)                         # 1/4, feature_channels[0]
+        inter = {"encfeat": (x, x2, x1, x0)}
+        # decoder_mono (DecoderFeature.forward :706-711)
+        y = self._fuse("upconv_3", x, None, None)
+        y = self._fuse("upconv_2", y, x2, (H7, W7))
+        ref_feat = self._fuse("upconv_1", y, x1, (H4, W4))                    # [.., dec[1] + 2]
+        inter["ref_feat"] = ref_feat
+        Cf = cfg["decoder_channels"][1]
+        feat = ref_feat.chan(0, Cf)
+        P4 = H4 * W4
+        # regress_depth (:806-838)
+        t = self.conv(feat, self.dreg[0], 3, Map(H4, W4, N_BINS, dev), act=ACT_RELU)
+        logits = self.conv(t, self.dreg[1], 1, Map(H4, W4, N_BINS, dev))
+        flow = torch.zeros(P4, 6, dtype=torch.float32, device=dev)            # coords1 - coords0 (:925-927)
+        call("gsr_dn_depth_expectation", P4, N_BINS, ptr(logits.t), logits.ld, MIN_VAL, MAX_VAL, REGRESS_SCALE,
+             ptr(flow), 6, _st())
+        # pred_normal (:840-850)
+        n = self.conv(feat, self.npred[0], 3, Map(H4, W4, 128, dev), act=ACT_RELU)
+        n = self.conv(n, self.npred[1], 1, Map(H4, W4, 128, dev), act=ACT_RELU)
+        n = self.conv(n, self.npred[2], 1, Map(H4, W4, 128, dev), act=ACT_RELU)
+        n = self.conv(n, self.npred[3], 1, Map(H4, W4, 3, dev))
+        nconf = ref_feat.chan(Cf + 1, 1)
+        call("gsr_dn_normal_head", P4, ptr(n.t), n.ld, ptr(nconf.t), nconf.ld, ptr(flow[:, 2:]), 6, _st())
+        flow[:, 1] = ref_feat.t[:, Cf].float()                                # depth confidence channel
+        inter["depth_init"] = flow.clone()
+        # context encoder (:919-921) on (x_4, x_8, x_16) = (x0, x1, x2)
+        nets, ctxs = [], []
+        for lvl, src, zq in (("04", x0, self.zqr[0]), ("08", x1, self.zqr[1]), ("16", x2, self.zqr[2])):
+            hnet = self._residual_block(src, self.ctx[lvl][0])
+            self.copy(hnet, hnet, act=ACT_TANH)                               # net = tanh(.)
+            c = self._residual_block(src, self.ctx[lvl][1])
+            ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev), relu_in=True)  # zqr(relu(.)) -> [cz|cr|cq]
+            nets.append(hnet)
+            ctxs.append(ctx)
+        flow16 = Map(H4, W4, 6, dev)
+        C2 = self.gru["gru08"]["C"]
+        for _ in range(cfg["iters"]):                                          # update loop (:945-975)
+            call("gsr_dn_cvt_f32_f16", P4, 6, ptr(flow), 6, ptr(flow16.t), flow16.ld, _st())
+            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
+            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
+            self._gru("gru16", nets[1], ctxs[1],
+                      [self.resize(self._pool2x(nets[0]), H7, W7, RESIZE_BILINEAR_AC),
+                       self.resize(nets[2], H7, W7, RESIZE_BILINEAR_AC)])
+            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
+            self._gru("gru16", nets[1], ctxs[1],
+                      [self.resize(self._pool2x(nets[0]), H7, W7, RESIZE_BILINEAR_AC),
+                       self.resize(nets[2], H7, W7, RESIZE_BILINEAR_AC)])
+            self._gru("gru08", nets[0], ctxs[0], [flow16, self.resize(nets[1], H4, W4, RESIZE_BILINEAR_AC)])
+            # flow head (:282-297): [conv1d | conv1n] in one GEMM, then the two 3x3 output convs
+            f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev), act=ACT_RELU)
+            rows = self._buf("fh_rows", (P4, self.fh2d.kp))
+            for lin, c0, o0, no in ((self.fh2d, 0, 0, 2), (self.fh2n, C2, 2, 4)):
+                part = f1.chan(c0, C2)
+                call("gsr_dn_im2col", H4, W4, C2, part.ld, 3, 1, 1, H4, W4, lin.kp, ptr(part.t), ptr(rows), 0, _st())
+                self.gemm(P4, lin, rows, lin.kp, residual=flow[:, o0:], ldr=6, out32=flow[:, o0:], ldo32=6)
+        # mask head of the last iteration (:309-313, 969) and convex upsampling (:870-884, 985-987)
+        m1 = self.conv(nets[0], self.mask1, 3, Map(H4, W4, C2, dev), act=ACT_RELU)
+        mask = self.conv(m1, self.mask2, 1, Map(H4, W4, self.mask2.n, dev))
+        self.copy(mask, mask, a=0.25)
+        Fu = 4
+        depth = torch.empty(1, 1, H4 * Fu, W4 * Fu, dtype=torch.float32, device=dev)
+        conf = torch.empty_like(depth)
+        normal = torch.empty(1, 4, H4 * Fu, W4 * Fu, dtype=torch.float32, device=dev)
+        call("gsr_dn_convex_upsample", H4, W4, Fu, ptr(flow), ptr(mask.t), mask.ld, MIN_VAL, MAX_VAL, REGRESS_SCALE,
+             ptr(depth), ptr(conf), ptr(normal), _st())
+        if return_intermediates:
+            return depth, conf, normal, inter
+        return depth, conf, normal
+
+    @torch.no_grad()
+    def inference(self, data: Dict[str, torch.Tensor]):
+        depth, conf, normal = self.decode(self.encode(data["input"]))
+        return depth, conf, {"prediction_normal": normal, "prediction": depth, "confidence": conf}
+
+    # ------------------------------------------------------------------ bookkeeping
+    def flops(self) -> Dict[str, float]:
+        """Dense FLOPs of one inference (2 x MACs of every GEMM and of attention)."""
+        D, n, d = self.D, self.n_tok, self.depth
+        enc = d * (2 * n * D * (3 * D + D + 8 * D) + 4 * n * n * D) + 2 * self.gh * self.gw * 588 * D
+        return {"encoder": float(enc)}

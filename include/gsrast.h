@@ -420,6 +420,66 @@ int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_top, int pa
                         int pad_left, int pad_right, int H, int W, float scale, float lo, float hi,
                         int do_clamp, float *out, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * B10: the dense monocular depth network on the matrix cores (csrc/depthnet.hip).
+ * Replaces the torch.hub Metric3D v2 model behind `model.inference({"input": rgb})`
+ * (gs_init_compare/depth_prediction/predictors/metric3d.py:27-31, 87-88); architecture:
+ * third_party/metric3d/mono/model/backbones/ViT_DINO_reg.py:755-1270 and
+ * .../decode_heads/RAFTDepthNormalDPTDecoder5.py:736-1035. All `void *` operands are fp16
+ * (IEEE half) device buffers, `float *` fp32; activations are row-major [rows, ld] with
+ * rows = tokens or pixels (NHWC maps), weights [N, K] as nn.Linear / flattened conv weights
+ * with K padded to a multiple of 64 by zeros.
+ * --------------------------------------------------------------------------*/
+/* out = residual + gamma * act(A[M,K] W[N,K]^T + bias): v_mfma_f32_32x32x16_f16, fp32 accumulate.
+ * act: 0 none, 1 GELU(erf), 2 ReLU, 3 sigmoid, 4 tanh. bias/gamma [N] fp32 or NULL; residual
+ * fp32 [M,ldr] and/or residual16 fp16 [M,ldr16] or NULL (may alias the outputs); out16 and/or
+ * out32 receive the result. K % 64 == 0, lda >= K, lda % 8 == 0. */
+int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W, const float *bias, int act,
+                const float *gamma, const float *residual, int ldr, const void *residual16, int ldr16,
+                void *out16, int ldo16, float *out32, int ldo32, void *stream);
+/* LayerNorm over the last dimension of [M,D] (fp32 or fp16 input), optional ReLU. */
+int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,
+                     const float *beta, float eps, void *out16, int ldo16, float *out32, int ldo32,
+                     int relu, void *stream);
+/* Multi-head self-attention, head_dim 64 (Attention.forward, ViT_DINO_reg.py:430-470):
+ * qkv fp16 [n_tok, ld >= 3*heads*64] as the qkv Linear writes it ([3][heads][64] per token);
+ * vt_scratch fp16 [heads*64*n_pad] (n_pad = n_tok rounded up to 64); out fp16 [n_tok, ldo]. */
+int gsr_dn_attention(int n_tok, int n_pad, int heads, const void *qkv, int ld, void *vt_scratch,
+                     float scale, void *out, int ldo, void *stream);
+/* Patch-embedding rows of an NCHW fp32 image [3,H,W]: [H/P*W/P, K_pad] fp16, column
+ * c*P*P + ky*P + kx (PatchEmbed.proj, ViT_DINO_reg.py:212). */
+int gsr_dn_patch_rows(int H, int W, int P, int K_pad, const float *img, void *rows, void *stream);
+/* im2col rows of a KSxKS convolution over an NHWC fp16 map [H*W, ldi] (C channels used):
+ * [Ho*Wo, K_pad], column (ky*KS + kx)*C + c; relu != 0 applies ReLU to the gathered values. */
+int gsr_dn_im2col(int H, int W, int C, int ldi, int KS, int stride, int pad, int Ho, int Wo, int K_pad,
+                  const void *in, void *rows, int relu, void *stream);
+/* NHWC resize: mode 0 nearest, 1 bilinear align_corners=True, 2 bilinear align_corners=False. */
+int gsr_dn_resize(int Hi, int Wi, int C, const void *in, int ldi, int Ho, int Wo, void *out, int ldo,
+                  int mode, void *stream);
+/* F.avg_pool2d(x, 3, stride=2, padding=1) on an NHWC map (pool2x, decoder :333). */
+int gsr_dn_avgpool3s2(int Hi, int Wi, int C, const void *in, int ldi, void *out, int ldo, void *stream);
+/* out[p, 0:C] = act(a * in[p, 0:C] (+ out[p, 0:C])) over strided channel slices. */
+int gsr_dn_slice(int64_t P, int C, const void *in, int ldi, void *out, int ldo, float a, int accumulate,
+                 int act, void *stream);
+/* ConvGRU gate algebra (decoder :318-330). stage 0: zr = [convz(hx) | convr(hx)] [P,2C], ctx =
+ * [cz | cr | cq] [P,3C]: writes z = sigmoid(.) and rh = sigmoid(.) * h. stage 1: zr = convq([r*h, x])
+ * [P,C]: h = (1 - z) h + z tanh(zr + cq). */
+int gsr_dn_gru_gate(int64_t P, int C, int stage, const void *zr, int ldzr, const void *ctx, int ldc,
+                    void *h, int ldh, void *z, int ldz, void *rh, int ldrh, void *stream);
+/* regress_depth (decoder :806-838): softmax over `bins` logits, expectation over log-spaced bins in
+ * [min_val, max_val], clamp, (d - max_val) / regress_scale -> out[p*ldo]. */
+int gsr_dn_depth_expectation(int64_t P, int bins, const void *logits, int ld, float min_val,
+                             float max_val, float regress_scale, float *out, int ldo, void *stream);
+/* pred_normal's norm_normalize (decoder :252-258, 840-850): out[p*ldo + 0..3]. */
+int gsr_dn_normal_head(int64_t P, const void *nrm, int ldn, const void *conf, int ldc, float *out,
+                       int ldo, void *stream);
+/* upsample_flow (decoder :870-884) fused with the output heads (:985-987): flow fp32 [H*W,6],
+ * mask fp16 [H*W, ldm >= 9 F F] -> depth, confidence [H F, W F] and normal [4, H F, W F] fp32. */
+int gsr_dn_convex_upsample(int H, int W, int F, const float *flow, const void *mask, int ldm,
+                           float min_val, float max_val, float regress_scale, float *depth,
+                           float *conf, float *normal, void *stream);
+int gsr_dn_cvt_f32_f16(int64_t P, int C, const float *in, int ldi, void *out, int ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+"""Deterministic pseudo-random tensors for the depth-network fixtures (no reference code, no
+torch RNG): values come from integer arithmetic on the element index and a CRC of the tensor
+name, so the generator (build container) and the tests (GPU box, other CPU) construct
+bit-identical weights and inputs without storing them. Real Metric3D weights are a remote
+download and unavailable offline: the fixtures pin the ARCHITECTURE with these weights."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def uniform(name: str, shape, lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    x = np.arange(n, dtype=np.uint64) * np.uint64(6364136223846793005) + np.uint64(zlib.crc32(name.encode()) * 2654435761 + 1442695040888963407)
+    x ^= x >> np.uint64(33)
+    x *= np.uint64(0xFF51AFD7ED558CCD)
+    x ^= x >> np.uint64(33)
+    u = (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)          # [0, 1)
+    return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32).reshape(shape))
+
+
+def init_param(key: str, shape) -> torch.Tensor:
+    """Initialisation rule by parameter name (encoder and decoder state-dict keys of the
+    reference modules): magnitudes chosen so that activations stay O(1) through the depth."""
+    shape = tuple(shape)
+    leaf = key.split(".")[-1]
+    if leaf == "gamma":                                   # LayerScale
+        return uniform(key, shape, 0.3, 1.0)
+    if "norm" in key or key.endswith("downsample.1.weight") or key.endswith("downsample.1.bias"):
+        return uniform(key, shape, 0.7, 1.3) if leaf == "weight" else uniform(key, shape, -0.1, 0.1)
+    if key in ("cls_token", "register_tokens", "mask_token"):
+        return uniform(key, shape, -0.5, 0.5)
+    if key == "pos_embed":
+        return uniform(key, shape, -0.3, 0.3)
+    if leaf == "bias":
+        return uniform(key, shape, -0.05, 0.05)
+    if leaf == "weight":
+        if key.endswith("read_1.sample.weight"):          # ConvTranspose2d [Cin, Cout, k, k]
+            fan_in = shape[0]
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        a = (3.0 / fan_in) ** 0.5                          # uniform with variance 1 / fan_in
+        return uniform(key, shape, -a, a)
+    raise KeyError(key)
+
+
+def fill(module_or_shapes) -> dict:
+    """state dict {key: tensor} for a torch module (its own keys/shapes) or a {key: shape} dict."""
+    if hasattr(module_or_shapes, "state_dict"):
+        shapes = {k: tuple(v.shape) for k, v in module_or_shapes.state_dict().items()}
+    else:
+        shapes = module_or_shapes
+    return {k: init_param(k, s) for k, s in shapes.items()}
+
+
+def image(H: int, W: int) -> torch.Tensor:
+    """Network input [1,3,H,W]: a smooth pattern plus hash noise, ImageNet-normalised range."""
+    y, x = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    base = torch.stack([torch.sin(x / 17.0) + torch.cos(y / 11.0), torch.sin((x + y) / 23.0), torch.cos(x / 7.0) * torch.sin(y / 13.0)])
+    # sin/cos differ in the last bits between libms: quantise to 1/256 so the input is exact
+    base = torch.round(base * 256.0) / 256.0
+    return (base + uniform("image", (3, H, W), -0.5, 0.5))[None].contiguous()

@@ -1,0 +1,96 @@
+"""Generate tests/golden/depthnet_golden.npz by running the REFERENCE's own vendored Metric3D
+modules (architecture spec of SURVEY.md row B10):
+
+  gs_init_compare/third_party/metric3d/mono/model/backbones/ViT_DINO_reg.py
+      DinoVisionTransformer (:755), vit_large_reg block shapes (:1227)
+  gs_init_compare/third_party/metric3d/mono/model/decode_heads/RAFTDepthNormalDPTDecoder5.py
+      RAFTDepthNormalDPT5 (:736-1035)
+
+Run only in the build container: python tests/golden/make_depthnet_golden.py
+
+Both files import with plain torch (xformers is optional there and absent -> their own
+fallback attention). They are loaded by file path; nothing is stubbed. Weights and inputs are
+the deterministic tensors of tests/golden/dn_weights.py (the real weights are a torch.hub
+download, unavailable offline), so the fixture holds OUTPUT activations only:
+"structurally pinned, random weights". One buffer the decoder would create with
+device="cuda" (get_bins, :797-802) is registered from here with the same formula on the CPU.
+"""
+import importlib.util
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import dn_weights as DW  # noqa: E402
+
+BASE = "/root/reference/gs_init_compare/third_party/metric3d/mono/model"
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+V = _load("ref_vit", BASE + "/backbones/ViT_DINO_reg.py")
+D = _load("ref_dec", BASE + "/decode_heads/RAFTDepthNormalDPTDecoder5.py")
+
+
+class NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+def vit(embed_dim, heads, depth):
+    m = V.DinoVisionTransformer(img_size=518, patch_size=14, embed_dim=embed_dim, depth=depth, num_heads=heads,
+                                mlp_ratio=4, block_fn=V.partial(V.Block, attn_class=V.MemEffAttention),
+                                num_register_tokens=4).eval()
+    m.load_state_dict(DW.fill(m))
+    return m
+
+
+out = {}
+H, W = 112, 168
+img = DW.image(H, W)
+torch.set_num_threads(8)
+with torch.no_grad():
+    # (a) reduced ViT: 128-d, 2 heads, 2 blocks
+    enc = vit(128, 2, 2)
+    feats, meta = enc(img)
+    out["vit128_tokens"] = feats[0][0].numpy()                               # [101,128] final-norm tokens
+    out["vit128_meta"] = np.array(meta, np.int64)
+    # (b) vit_large_reg block shapes (1024-d, 16 heads), 2 blocks
+    encL = vit(1024, 16, 2)
+    featsL, _ = encL(img)
+    out["vit1024_tokens"] = featsL[0][0].numpy().astype(np.float16)
+    # (c) reduced decoder on the tokens of (a)
+    cfg = NS(model=NS(decode_head=NS(in_channels=[128] * 4, use_cls_token=True, feature_channels=[32, 64, 128, 256],
+                                     decoder_channels=[16, 32, 64, 128, 128], up_scale=7,
+                                     hidden_channels=[16, 16, 16, 16], n_gru_layers=3, n_downsample=2, iters=3,
+                                     slow_fast_gru=True, num_register_tokens=4)),
+             data_basic=NS(depth_normalize=(0.1, 200)))
+    dec = D.RAFTDepthNormalDPT5(cfg).eval()
+    dec.load_state_dict(DW.fill(dec))
+    bins = torch.exp(torch.linspace(math.log(0.1), math.log(200), 256)).unsqueeze(0)
+    dec.register_buffer("depth_expectation_anchor", bins, persistent=False)
+    # intermediates through the module's own sub-blocks (for localising a mismatch)
+    B, gh, gw, _, _, nreg = meta
+    vf = [[ft[:, 1 + nreg:, :].view(B, gh, gw, 128), ft[:, 0:1 + nreg, :].view(B, 1, 1, 128 * (1 + nreg))] for ft in feats]
+    ef = dec.token2feature(vf)
+    for i, t in enumerate(ef):
+        out[f"dec_encfeat{i}"] = t[0].permute(1, 2, 0).numpy().astype(np.float16)      # NHWC
+    ref_feat = dec.decoder_mono(ef)
+    out["dec_ref_feat"] = ref_feat[0].permute(1, 2, 0).numpy().astype(np.float16)
+    o = dec([feats, meta])
+    out["dec_depth"] = o["prediction"][0, 0].numpy()
+    out["dec_conf"] = o["confidence"][0, 0].numpy()
+    out["dec_normal"] = o["prediction_normal"][0].numpy()
+    for k in ("dec_depth", "dec_conf", "dec_normal", "dec_ref_feat", "vit128_tokens", "vit1024_tokens"):
+        print(k, out[k].shape, float(np.abs(out[k].astype(np.float32)).mean()), float(np.abs(out[k].astype(np.float32)).max()))
+np.savez_compressed(HERE / "depthnet_golden.npz", **out)
+print("wrote depthnet_golden.npz")
