@@ -107,6 +107,7 @@ class Metric3DNet:
         self._prep_encoder({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
         self._prep_decoder({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
         self._scratch: Dict[str, torch.Tensor] = {}
+        self.flop_count = None          # set to 0.0 to accumulate the dense FLOPs of the next calls
 
     # ------------------------------------------------------------------ weights
     def _prep_encoder(self, sd):
@@ -174,7 +175,10 @@ class Metric3DNet:
                     rb[n] = (f32(sd[p + f"0.{n}.weight"]), f32(sd[p + f"0.{n}.bias"]))
                 if p + "0.downsample.0.weight" in sd:
                     rb["ds"] = conv(p + "0.downsample.0")
-                    rb["norm3"] = (f32(sd[p + "0.norm3.weight"]), f32(sd[p + "0.norm3.bias"]))
+                    # `downsample = Sequential(conv, self.norm3)` (decoder :396-398): ONE LayerNorm
+                    # under two names; load_state_dict visits `downsample.1` last, so it wins
+                    n3 = p + ("0.downsample.1" if p + "0.downsample.1.weight" in sd else "0.norm3")
+                    rb["norm3"] = (f32(sd[n3 + ".weight"]), f32(sd[n3 + ".bias"]))
                 heads.append(rb)
             self.ctx[lvl] = heads
         self.zqr = [conv(f"context_zqr_convs.{i}") for i in range(3)]
@@ -203,6 +207,8 @@ class Metric3DNet:
 
     def gemm(self, M, lin: _Lin, A, lda, act=ACT_NONE, gamma=None, residual=None, ldr=0, residual16=None,
              ldr16=0, out16=None, ldo16=0, out32=None, ldo32=0):
+        if getattr(self, "flop_count", None) is not None:
+            self.flop_count += 2.0 * M * lin.n * lin.k
         call("gsr_dn_gemm", M, lin.n, lin.kp, ptr(A), lda, ptr(lin.w), ptr(lin.b), act, ptr(gamma),
              ptr(residual), ldr, ptr(residual16), ldr16, ptr(out16), ldo16, ptr(out32), ldo32, _st())
 
@@ -262,6 +268,8 @@ class Metric3DNet:
             call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n1w"]), ptr(b["n1b"]), 1e-6, ptr(xn), D,
                  None, 0, 0, _st())
             self.gemm(n_tok, b["qkv"], xn, D, out16=qkv, ldo16=3 * D)
+            if self.flop_count is not None:
+                self.flop_count += 4.0 * n_tok * n_tok * D
             call("gsr_dn_attention", n_tok, n_pad, self.heads, ptr(qkv), 3 * D, ptr(vt), scale, ptr(att), D, _st())
             self.gemm(n_tok, b["proj"], att, D, gamma=b["ls1"], residual=x, ldr=D, out32=x, ldo32=D)
             call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n2w"]), ptr(b["n2b"]), 1e-6, ptr(xn), D,
@@ -288,8 +296,12 @@ class Metric3DNet:
         return out
 
     def _conv_block(self, x: Map, c1, c2) -> Map:
-        """ConvBlock (decoder :520-548): x + conv2(relu(conv1(relu(x))))."""
-        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev), relu_in=True)
+        """ConvBlock (decoder :520-548). Its activation is `nn.ReLU(inplace=True)` applied to the
+        INPUT tensor, so the block computes relu(x) + conv2(relu(conv1(relu(x)))) and leaves its
+        input rectified for every later reader -- the context encoder sees relu'd 1/14 and 1/7
+        features (decoder :911-919 after :899). Reproduced, side effect included."""
+        self.copy(x, x, act=ACT_RELU)
+        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev))
         return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev), relu_in=True, residual=x)
 
     def _fuse(self, name, x1: Map, x2: Optional[Map], size) -> Map:
@@ -367,7 +379,9 @@ class Metric3DNet:
         # the 1x1 conv commutes with the nearest upsampling: convolve at 1/14, then replicate
         x0s = self.conv(r0, self.read0_conv, 1, Map(gh, gw, self.read0_conv.n, dev))
         x0 = self.resize(x0s, H4, W4, RESIZE_NEAREST)                         # 1/4, feature_channels[0]
-        inter = {"encfeat": (x, x2, x1, x0)}
+        inter = {}
+        if return_intermediates:      # copies: the fusion below rectifies x, x2, x1 in place
+            inter["encfeat"] = tuple(Map(m.H, m.W, m.C, dev, ld=m.ld, t=m.t.clone()) for m in (x, x2, x1, x0))
         # decoder_mono (DecoderFeature.forward :706-711)
         y = self._fuse("upconv_3", x, None, None)
         y = self._fuse("upconv_2", y, x2, (H7, W7))
@@ -400,6 +414,10 @@ class Metric3DNet:
             ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev), relu_in=True)  # zqr(relu(.)) -> [cz|cr|cq]
             nets.append(hnet)
             ctxs.append(ctx)
+        if return_intermediates:
+            inter["nets"] = [Map(m.H, m.W, m.C, dev, ld=m.ld, t=m.t.clone()) for m in nets]
+            inter["ctxs"] = ctxs
+            inter["deltas"] = []
         flow16 = Map(H4, W4, 6, dev)
         C2 = self.gru["gru08"]["C"]
         for _ in range(cfg["iters"]):                                          # update loop (:945-975)
@@ -417,10 +435,14 @@ class Metric3DNet:
             # flow head (:282-297): [conv1d | conv1n] in one GEMM, then the two 3x3 output convs
             f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev), act=ACT_RELU)
             rows = self._buf("fh_rows", (P4, self.fh2d.kp))
+            if return_intermediates:
+                before = flow.clone()
             for lin, c0, o0, no in ((self.fh2d, 0, 0, 2), (self.fh2n, C2, 2, 4)):
                 part = f1.chan(c0, C2)
                 call("gsr_dn_im2col", H4, W4, C2, part.ld, 3, 1, 1, H4, W4, lin.kp, ptr(part.t), ptr(rows), 0, _st())
                 self.gemm(P4, lin, rows, lin.kp, residual=flow[:, o0:], ldr=6, out32=flow[:, o0:], ldo32=6)
+            if return_intermediates:
+                inter["deltas"].append(flow - before)
         # mask head of the last iteration (:309-313, 969) and convex upsampling (:870-884, 985-987)
         m1 = self.conv(nets[0], self.mask1, 3, Map(H4, W4, C2, dev), act=ACT_RELU)
         mask = self.conv(m1, self.mask2, 1, Map(H4, W4, self.mask2.n, dev))
@@ -440,9 +462,3 @@ class Metric3DNet:
         depth, conf, normal = self.decode(self.encode(data["input"]))
         return depth, conf, {"prediction_normal": normal, "prediction": depth, "confidence": conf}
 
-    # ------------------------------------------------------------------ bookkeeping
-    def flops(self) -> Dict[str, float]:
-        """Dense FLOPs of one inference (2 x MACs of every GEMM and of attention)."""
-        D, n, d = self.D, self.n_tok, self.depth
-        enc = d * (2 * n * D * (3 * D + D + 8 * D) + 4 * n * n * D) + 2 * self.gh * self.gw * 588 * D
-        return {"encoder": float(enc)}

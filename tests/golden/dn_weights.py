@@ -26,7 +26,9 @@ def init_param(key: str, shape) -> torch.Tensor:
     leaf = key.split(".")[-1]
     if leaf == "gamma":                                   # LayerScale
         return uniform(key, shape, 0.3, 1.0)
-    if "norm" in key or key.endswith("downsample.1.weight") or key.endswith("downsample.1.bias"):
+    segs = key.split(".")
+    is_norm = any(sg in ("norm", "norm1", "norm2", "norm3") for sg in segs) or segs[-2:-1] == ["1"] and "downsample" in segs
+    if is_norm:
         return uniform(key, shape, 0.7, 1.3) if leaf == "weight" else uniform(key, shape, -0.1, 0.1)
     if key in ("cls_token", "register_tokens", "mask_token"):
         return uniform(key, shape, -0.5, 0.5)

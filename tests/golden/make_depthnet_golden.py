@@ -86,7 +86,24 @@ with torch.no_grad():
         out[f"dec_encfeat{i}"] = t[0].permute(1, 2, 0).numpy().astype(np.float16)      # NHWC
     ref_feat = dec.decoder_mono(ef)
     out["dec_ref_feat"] = ref_feat[0].permute(1, 2, 0).numpy().astype(np.float16)
+    # heads and context encoder on a fresh copy of the features (decoder_mono rectified `ef`
+    # in place, exactly what the full forward below hands to the context encoder)
+    fmap = ref_feat[:, :-2]
+    dpred, _ = dec.regress_depth(fmap)
+    npred = dec.pred_normal(fmap, ref_feat[:, -1:])
+    depth_init = torch.cat((dpred, ref_feat[:, -2:-1], npred), dim=1)
+    out["dec_depth_init"] = depth_init[0].permute(1, 2, 0).numpy()                       # [H4, W4, 6]
+    cnet = dec.context_feature_encoder(ef[::-1])
+    for i, pair in enumerate(cnet):
+        out[f"dec_net{i}"] = torch.tanh(pair[0])[0].permute(1, 2, 0).numpy().astype(np.float16)
+        out[f"dec_ctx{i}"] = dec.context_zqr_convs[i](torch.relu(pair[1]))[0].permute(1, 2, 0).numpy().astype(np.float16)
+    deltas = []
+    hook = dec.update_block.register_forward_hook(
+        lambda m, i, o: deltas.append(o[2][0].permute(1, 2, 0).numpy()) if isinstance(o, tuple) and len(o) == 3 else None)
     o = dec([feats, meta])
+    hook.remove()
+    for i, dl in enumerate(deltas):
+        out[f"dec_delta{i}"] = dl
     out["dec_depth"] = o["prediction"][0, 0].numpy()
     out["dec_conf"] = o["confidence"][0, 0].numpy()
     out["dec_normal"] = o["prediction_normal"][0].numpy()

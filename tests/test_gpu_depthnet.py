@@ -250,6 +250,13 @@ def test_decoder_vs_reference_golden(N):
         _close(m.t[:, :m.C].reshape(m.H, m.W, m.C), ref, what=f"encfeat{i}")
     rf = inter["ref_feat"]
     _close(rf.t[:, :rf.C].reshape(rf.H, rf.W, rf.C), G["dec_ref_feat"].astype(np.float32), what="ref_feat")
+    _close(inter["depth_init"].view(rf.H, rf.W, 6), G["dec_depth_init"], what="depth_init")
+    for i in range(3):
+        m, c = inter["nets"][i], inter["ctxs"][i]
+        _close(m.t[:, :m.C].reshape(m.H, m.W, m.C), G[f"dec_net{i}"].astype(np.float32), what=f"net{i}")
+        _close(c.t[:, :c.C].reshape(c.H, c.W, c.C), G[f"dec_ctx{i}"].astype(np.float32), what=f"ctx{i}")
+    for i, dl in enumerate(inter["deltas"]):
+        _close(dl.view(rf.H, rf.W, 6), G[f"dec_delta{i}"], max_frac=4e-2, mean_frac=2e-2, what=f"delta_flow{i}")
     assert depth.shape == (1, 1, 112, 168) and normal.shape == (1, 4, 112, 168)
     _close(depth[0, 0], G["dec_depth"], what="depth")
     _close(conf[0, 0], G["dec_conf"], max_frac=4e-2, mean_frac=1e-2, what="confidence")
