@@ -141,21 +141,26 @@ class GatherRowsSync:
     (36 MB per rank at 1 M Gaussians instead of a 236 MB all-reduce), and every rank runs the
     projection backward over the cameras of ALL ranks (`C = world_size`, the batch path of
     `gsr_project_bwd_adam`), which also keeps the Adam update fused in the backward. Every
-    rank sums the views in rank order, so the replicas stay bit-identical.
+    rank sums the views in rank order, so the replicas stay bit-identical. The exchange is
+    pipelined over `chunks` Gaussian ranges: the all-gather of range k+1 (asynchronous, on RCCL's
+    stream) overlaps the projection backward + Adam of range k.
 
     Usage: `sync = GatherRowsSync(fused_adam, world, rank)`; before each step
     `sync.set_views(camtoworlds_all [W,4,4], Ks_all [W,3,3])` (row r = the camera rank r
     renders in this step, e.g. via `shard_views`); then the usual `train_step` with the local
     camera and `grad_sync=sync`. `close()` unhooks it."""
 
-    def __init__(self, fused_adam, world_size: int, rank: int, group=None):
+    def __init__(self, fused_adam, world_size: int, rank: int, group=None, chunks: int = 4,
+                 min_chunk: int = 4096):
         from .rendering import set_row_exchange
         self.world, self.rank, self.group = world_size, rank, group
         self.fused = fused_adam
+        self.chunks = max(1, int(chunks))
+        self.min_chunk = max(64, int(min_chunk))
         fused_adam.fuse_into_backward(True)
         set_row_exchange(self)
         self._views = None
-        self._buf = None
+        self._bufs = {}
 
     def set_views(self, camtoworlds_all, Ks_all) -> None:
         from .rendering import inverse4x4
@@ -163,28 +168,52 @@ class GatherRowsSync:
         viewmats, campos = inverse4x4(camtoworlds_all, translation_of="input")
         self._views = (viewmats, Ks_all.float().contiguous(), campos)
 
+    def chunk_bounds(self, N: int):
+        """Gaussian ranges of the pipeline, boundaries on multiples of 64 (a wave of the projection
+        backward, and 16-byte alignment of every per-Gaussian parameter row incl. the 180-byte shN)."""
+        k = min(self.chunks, max(1, N // self.min_chunk))
+        step = (N // k + 63) // 64 * 64
+        out, a = [], 0
+        while a < N:
+            b = N if len(out) == k - 1 else min(N, a + step)
+            out.append((a, b))
+            a = b
+        return out
+
     def exchange(self, rows, radii, N: int):
-        """Called by the projection backward: local rows [N,16] + radii -> all ranks' packed
-        rows [W*N,9] and all ranks' cameras."""
+        """Called by the projection backward: local rows [N,16] + radii -> the cameras of all
+        ranks and a list of chunks `(start, count, rows_all [W*count, 9], wait)`; the consumer
+        calls `wait()` and then runs the projection backward of that Gaussian range over the W
+        cameras. The all-gather of chunk k+1 is in flight (on RCCL's own stream) while chunk k is
+        being consumed: both are element-wise in the Gaussian index, so nothing else orders them."""
         from ._lib import call, ptr
         if self._views is None:
             raise RuntimeError("GatherRowsSync.set_views() must be called before every step")
         dev = rows.device
         W = self.world
-        if self._buf is None or self._buf.shape[0] != W * N:
-            self._buf = torch.empty(W * N, 9, dtype=torch.float32, device=dev)
-        mine = self._buf[self.rank * N:(self.rank + 1) * N]
-        call("gsr_pack_grad_rows", N, ptr(rows), ptr(radii), ptr(mine),
-             torch.cuda.current_stream().cuda_stream)
-        if W > 1:
-            if dist.get_backend(self.group) == "nccl":
-                dist.all_gather_into_tensor(self._buf, mine, group=self.group)   # in place
-            else:       # gloo (tests): list form, input must not alias the outputs
-                outs = [self._buf[r * N:(r + 1) * N] for r in range(W)]
-                dist.all_gather(outs, mine.clone(), group=self.group)
+        st = torch.cuda.current_stream().cuda_stream
+        nccl = W > 1 and dist.get_backend(self.group) == "nccl"
+        chunks = []
+        for a, b in self.chunk_bounds(N):
+            n = b - a
+            key = (a, n)
+            buf = self._bufs.get(key)
+            if buf is None:
+                if len(self._bufs) > 64:
+                    self._bufs.clear()          # the Gaussian count changed (densification)
+                buf = self._bufs[key] = torch.empty(W * n, 9, dtype=torch.float32, device=dev)
+            mine = buf[self.rank * n:(self.rank + 1) * n]
+            call("gsr_pack_grad_rows", n, rows.data_ptr() + 64 * a, radii.data_ptr() + 8 * a, ptr(mine), st)
+            work = None
+            if nccl:
+                work = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)   # in place
+            elif W > 1:     # gloo (tests): list form, input must not alias the outputs
+                outs = [buf[r * n:(r + 1) * n] for r in range(W)]
+                work = dist.all_gather(outs, mine.clone(), group=self.group, async_op=True)
+            chunks.append((a, n, buf, (work.wait if work is not None else (lambda: None))))
         vm, Ks, campos = self._views
         self._views = None
-        return self._buf, vm, Ks, campos, W
+        return chunks, vm, Ks, campos, W
 
     def __call__(self) -> None:          # train_step's grad_sync hook: nothing left to do
         return None

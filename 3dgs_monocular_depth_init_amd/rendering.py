@@ -232,32 +232,39 @@ class _ProjectSH(torch.autograd.Function):
         fusable = (ctx.split and sh_degree >= 0 and sh_b is not None and sh_b.shape[1] == 15
                    and activations == (ACT_EXP_SCALES | ACT_SIGMOID_OPAC)
                    and all(ctx.needs_input_grad[:6]))
-        rows_all = None
+        chunks = None
         if ex is not None:
             if (not fusable or C != 1 or v_depths is not None or v_comps is not None
                     or depth_channel >= 0):
                 raise NotImplementedError(
                     "row exchange: one colour-only view per rank per step, on the six raw parameters")
-            # every rank's 36-byte rows, and every rank's camera: the sum over the views is
-            # taken inside the projection backward, identically on all ranks
-            rows_all, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
+            # every rank's 36-byte rows, and every rank's camera: the sum over the views is taken
+            # inside the projection backward, identically on all ranks. The exchange is pipelined
+            # over Gaussian ranges: all-gather(k+1) runs while the backward of range k does.
+            chunks, vm_all, Ks_all, campos_all, W = ex.exchange(rows, radii, N)
         bo = _BACKWARD_OPTIMIZER
         if bo is not None and fusable:
             args = bo.claim((means, quats, scales, ctx.raw_opacities, sh_a, sh_b))
             if args is not None:
                 P, M, V, ss, bc2, beta1, beta2, eps = args
-                if rows_all is not None:
-                    call("gsr_project_bwd_adam", W, N, ptr(vm_all), ptr(Ks_all), ptr(campos_all),
-                         width, height, eps2d, sh_degree, None, ptr(rows_all), PACKED_ROW, None,
-                         None, -1, activations, ptr(opac_act), P, M, V, ss, bc2, beta1, beta2,
-                         eps, _stream())
+                if chunks is not None:
+                    PA = type(P)
+                    # bytes per Gaussian of means, quats, scales, opacities, sh0, shN
+                    row_bytes = (12, 16, 12, 4, 12, 180)
+                    for a0, n, rows_k, wait in chunks:
+                        wait()
+                        off = lambda arr: PA(*[(arr[t] or 0) + a0 * row_bytes[t] for t in range(6)])
+                        call("gsr_project_bwd_adam", W, n, ptr(vm_all), ptr(Ks_all), ptr(campos_all),
+                             width, height, eps2d, sh_degree, None, ptr(rows_k), PACKED_ROW, None,
+                             None, -1, activations, opac_act.data_ptr() + 4 * a0, off(P), off(M),
+                             off(V), ss, bc2, beta1, beta2, eps, _stream())
                     return (None,) * 10
                 call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
                      height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
                      ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
                      beta1, beta2, eps, _stream())
                 return (None,) * 10
-        if rows_all is not None:
+        if chunks is not None:
             # gathered rows, optimizer NOT fused (a step on which the strategy must see the
             # gradients before the update): the W-view gradients are written out, identical on
             # every rank, and the optimizer steps afterwards as in the reference's order
@@ -265,11 +272,15 @@ class _ProjectSH(torch.autograd.Function):
             v_means, v_quats, v_scales = (_grad_out("means", means), _grad_out("quats", quats),
                                           _grad_out("scales", scales))
             v_sh_a, v_sh_b = _grad_out("sh0", sh_a), _grad_out("shN", sh_b)
-            call("gsr_project_bwd_rows", W, N, ptr(means), ptr(quats), ptr(scales), ptr(vm_all),
-                 ptr(Ks_all), ptr(campos_all), width, height, eps2d, sh_degree, ptr(sh_a), 3,
-                 ptr(sh_b), 45, None, ptr(rows_all), PACKED_ROW, ptr(v_means), ptr(v_quats),
-                 ptr(v_scales), ptr(v_sh_a), 3, ptr(v_sh_b), 45, 16, activations, ptr(opac_act),
-                 ptr(v_opacities), _stream())
+            for a0, n, rows_k, wait in chunks:
+                wait()
+                call("gsr_project_bwd_rows", W, n, means.data_ptr() + 12 * a0, quats.data_ptr() + 16 * a0,
+                     scales.data_ptr() + 12 * a0, ptr(vm_all), ptr(Ks_all), ptr(campos_all), width,
+                     height, eps2d, sh_degree, sh_a.data_ptr() + 12 * a0, 3, sh_b.data_ptr() + 180 * a0,
+                     45, None, ptr(rows_k), PACKED_ROW, v_means.data_ptr() + 12 * a0,
+                     v_quats.data_ptr() + 16 * a0, v_scales.data_ptr() + 12 * a0,
+                     v_sh_a.data_ptr() + 12 * a0, 3, v_sh_b.data_ptr() + 180 * a0, 45, 16, activations,
+                     opac_act.data_ptr() + 4 * a0, v_opacities.data_ptr() + 4 * a0, _stream())
             return v_means, v_quats, v_scales, v_opacities, v_sh_a, v_sh_b, None, None, None, None
         if activations & ACT_SIGMOID_OPAC:
             v_opacities = _grad_out("opacities", opac_act)

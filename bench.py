@@ -88,7 +88,20 @@ def _cpu_baseline_worker(sample_n: int):
                                sh_degree=SH_DEGREE)
     (rc - target).abs().mean().backward()
     dt = time.perf_counter() - t0
-    print(json.dumps({"dt": dt, "cores": cores}))
+    # the reference's own CPU-runnable configuration c1 (10k Gaussians, 1 camera, 256x256),
+    # native size, median of 5 after one warm-up (SURVEY.md section 8d "CPU baseline beside it")
+    c1, vm1, K1, W1, H1 = scenes.config_c1()
+    t1 = torch.rand(1, H1, W1, 3, generator=torch.Generator().manual_seed(2))
+    times = []
+    for it in range(6):
+        p = {k: v.clone().requires_grad_(True) for k, v in c1.items()}
+        a = time.perf_counter()
+        rc, _, _ = O.rasterization(p["means"], p["quats"], p["scales"], p["opacities"],
+                                   torch.cat([p["sh0"], p["shN"]], 1), vm1, K1, W1, H1, sh_degree=SH_DEGREE)
+        (rc - t1).abs().mean().backward()
+        times.append(time.perf_counter() - a)
+    c1_dt = sorted(times[1:])[2]
+    print(json.dumps({"dt": dt, "cores": cores, "c1_dt": c1_dt}))
 
 
 def cpu_baseline(sample_n: int = 250_000, budget_s: float = 150.0):
@@ -108,6 +121,8 @@ def cpu_baseline(sample_n: int = 250_000, budget_s: float = 150.0):
                 "sample": f"CPU oracle did not finish within {budget_s:.0f} s ({type(e).__name__})"}
     dt = rec["dt"]
     return {**base, "cores": rec["cores"],
+            "c1_native": {"value": 1.0 / rec["c1_dt"], "unit": "iters/s", "ms_per_iter": rec["c1_dt"] * 1e3,
+                          "workload": "c1: 10k Gaussians, 1 camera 256x256, fwd+bwd, native size, median of 5"},
             # linear extrapolation in the Gaussian count (optimistic for the CPU)
             "value": (1.0 / dt) * (sample_n / N_GAUSS),
             "sample": (f"oracle/rasterization_oracle.py fwd+bwd, first {sample_n} of the 1M Gaussians, "
@@ -253,32 +268,99 @@ def main():
         torch.cuda.synchronize()
 
     dom = "gsr_rasterize_bwd"            # dominant kernel: compositing backward (A7)
-    for k in range(args.warmup):
-        step(k)
-    barrier()
+
+    def timed(n_warm: int, n_steps: int, k0: int, only=None):
+        """W untimed + K timed steps between barriers; returns (seconds, max over ranks; kernel times)."""
+        for k in range(n_warm):
+            step(k0 + k)
+        barrier()
+        lib.TIMERS = {}
+        lib.TIMER_ONLY = only
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            step(k0 + n_warm + k)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        kt = lib.kernel_times_ms()
+        lib.TIMERS = None
+        lib.TIMER_ONLY = None
+        if use_dist:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, kt
+
     # timed region: only the dominant kernel is bracketed by events (2 records per step);
     # the per-kernel breakdown is taken on a few extra, untimed steps afterwards so that
     # its ~25 event records per step do not sit in the measured host path
-    lib.TIMERS = {}
-    lib.TIMER_ONLY = {dom}
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    dt = time.perf_counter() - t0
-    dom_times = lib.kernel_times_ms()
-    lib.TIMERS = {}
-    lib.TIMER_ONLY = None
-    for k in range(5):
-        step(args.warmup + args.steps + k)
-    barrier()
-    times = lib.kernel_times_ms()
+    dt, dom_times = timed(args.warmup, args.steps, 0, only={dom})
+    _, times = timed(0, 5, args.warmup + args.steps)
     times[dom] = dom_times.get(dom, times.get(dom))
-    lib.TIMERS = None
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    k_next = args.warmup + args.steps + 5
+
+    # SURVEY.md section 8d's metric proper -- forward + full backward with the six parameter
+    # gradients MATERIALISED, optimizer excluded -- beside the headline (which fuses Adam into the
+    # backward and never writes the gradients: more work per step, fewer bytes)
+    metric_8d = None
+    if world == 1 and not use_dist and not args.no_optimizer:
+        R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+        saved = R._BACKWARD_OPTIMIZER
+        R.set_backward_optimizer(None)
+        opt_saved, args.no_optimizer = args.no_optimizer, True
+        try:
+            dt8, _ = timed(2, args.steps, k_next)
+        finally:
+            args.no_optimizer = opt_saved
+            R.set_backward_optimizer(saved)
+        k_next += 2 + args.steps
+        metric_8d = {"definition": "fwd + L1 + full backward, six gradient tensors written, no optimizer",
+                     "value": args.steps / dt8, "unit": "iters/s", "ms_per_step": dt8 / args.steps * 1e3}
+
+    # N > 1: the OTHER exchange too (north_star names the gradient all-reduce, the default is the
+    # equivalent all-gather of view-space rows), and the raw collectives' bus bandwidth
+    sync_modes, collectives = None, None
+    if use_dist and not args.no_optimizer:
+        this_mode = "gather" if gather else "allreduce"
+        sync_modes = {this_mode: {"ms_per_step": dt / args.steps * 1e3, "value": args.steps * world / dt}}
+        other = "allreduce" if gather else "gather"
+        if gather:
+            sync.close()
+            sync = distributed.GradSync(splats, world, force=use_dist)
+            sync.attach(optimizers)
+            gather = False
+        else:
+            rendering = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+            rendering.set_grad_arena(None)
+            optimizers.grad_sync = None
+            sync = distributed.GatherRowsSync(optimizers, world, rank)
+            gather = True
+        dt_o, _ = timed(3, args.steps, k_next)
+        k_next += 3 + args.steps
+        sync_modes[other] = {"ms_per_step": dt_o / args.steps * 1e3, "value": args.steps * world / dt_o}
+        # raw collectives on the real message sizes: bus bandwidth = 2(W-1)/W bytes / t (all-reduce),
+        # (W-1)/W total bytes / t (all-gather) -- BASELINE.md section 2
+        flat = torch.zeros(59 * N, dtype=torch.float32, device=dev)
+        rows_all = torch.zeros(world * N * 9, dtype=torch.float32, device=dev)
+        mine = rows_all[rank * N * 9:(rank + 1) * N * 9]
+
+        def coll(fn, reps=5):
+            fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            barrier()
+            return (time.perf_counter() - t0) / reps
+
+        t_ar = coll(lambda: dist.all_reduce(flat))
+        t_ag = coll(lambda: dist.all_gather_into_tensor(rows_all, mine)) if backend == "nccl" else None
+        collectives = {
+            "allreduce_59N_fp32": {"bytes": flat.numel() * 4, "ms": t_ar * 1e3,
+                                   "bus_GBps": 2 * (world - 1) / world * flat.numel() * 4 / t_ar / 1e9},
+            "allgather_9N_fp32": None if t_ag is None else {
+                "bytes_per_rank": N * 36, "ms": t_ag * 1e3,
+                "bus_GBps": (world - 1) / world * rows_all.numel() * 4 / t_ag / 1e9}}
+        del flat, rows_all
 
     info = info_box["info"]
     V = int((info["radii"] > 0).all(-1).sum().item())
@@ -291,25 +373,39 @@ def main():
     dom_bytes = bwd_b["raster_bwd_pix"] + bwd_b["raster_bwd_gather"] + bwd_b["raster_bwd_atomics"]
     dom_ms = times.get(dom, (0, float("nan")))[1]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else None
-    traffic = None
-    pmc = ROOT / "profiles" / "pmc_traffic.json"
+    # Counter-derived figures come from the COMMITTED rocprofv3 PMC digest of this same workload
+    # (tools/profile_round.sh -> tools/digest_profiles.py): they are tagged with their source
+    # file and the commit they were taken at, so a stale digest is visible in the line.
+    traffic, valu_issue, pmc_src = None, None, None
+    pmc = ROOT / "profiles" / "pmc_dominant.json"
     if pmc.exists():
-        traffic = json.loads(pmc.read_text()).get(dom)
-    # The compositing kernels are bound by fp32 VALU issue, which the
-    # hbm|mfma roofline cannot express: report it beside the HBM figure. Instruction count per
-    # launch from the committed SQ_INSTS_VALU pass; cycles per wave64 instruction per SIMD =
-    # kernel time x 1024 SIMDs x 2.4 GHz / instructions. Reference rates measured with
-    # tools/dbg/ubench/valu_rate.hip on the same hardware: a dependent chain issues at 4.3
-    # cycles per instruction whatever the occupancy, independent instructions at 2.7.
-    valu_issue = None
-    pv = ROOT / "profiles" / "pmc_valu.json"
-    if pv.exists() and dom_ms == dom_ms and dom_ms > 0:
-        n_inst = json.loads(pv.read_text()).get(dom)
-        if n_inst:
-            cpi = dom_ms * 1e-3 * 2.4e9 * 1024 / n_inst
-            valu_issue = {"insts_per_launch": n_inst, "simds": 1024, "clock_ghz": 2.4,
-                          "cycles_per_inst": cpi, "dependent_chain_cycles_per_inst": 4.3,
-                          "independent_cycles_per_inst": 2.7, "frac_of_independent_rate": 2.7 / cpi}
+        d = json.loads(pmc.read_text())
+        pmc_src = {"file": "profiles/pmc_dominant.json", "digest_of": d.get("source"), "commit": d.get("commit")}
+        kc = d.get("kernels", {}).get(dom, {})
+        if "FETCH_SIZE" in kc and "WRITE_SIZE" in kc:
+            # gfx950: FETCH_SIZE / WRITE_SIZE in KiB, FETCH counts half of the bytes of wide reads
+            traffic = int((2 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024)
+        if "SQ_INSTS_VALU" in kc and "GRBM_GUI_ACTIVE" in kc:
+            # The compositing kernels are bound by VALU issue + wave stalls, not by HBM (DESIGN.md
+            # section 4): cycles per wave64 VALU instruction per SIMD from counters alone
+            # (GRBM_GUI_ACTIVE is summed over the 8 XCDs; no clock is assumed), beside the rates
+            # the VALU itself sustains, measured by tools/ubench/valu_rate.hip with the clock
+            # measured in-kernel (profiles/r02_valu_rate.jsonl).
+            cycles = kc["GRBM_GUI_ACTIVE"] / 8.0
+            cpi = cycles * 1024 / kc["SQ_INSTS_VALU"]
+            ref = {}
+            ub = ROOT / "profiles" / "r02_valu_rate.jsonl"
+            if ub.exists():
+                for ln in ub.read_text().splitlines():
+                    r = json.loads(ln)
+                    if r["chip"].startswith("all") and r["waves_per_simd"] == 4:
+                        ref[r["mode"]] = r["cycles_per_inst_per_simd"]
+            valu_issue = {"insts_per_launch": int(kc["SQ_INSTS_VALU"]), "simds": 1024,
+                          "cycles_per_launch": cycles, "cycles_per_inst_per_simd": cpi,
+                          "ubench_4_waves_per_simd": {k: ref.get(k) for k in ("indep_fma", "chain1", "exp_quarter",
+                                                                             "composite1", "composite2")},
+                          "ubench_source": "profiles/r02_valu_rate.jsonl",
+                          "frac_of_indep_fma_rate": (ref["indep_fma"] / cpi) if "indep_fma" in ref else None}
 
     if rank == 0:
         line = {
@@ -324,7 +420,7 @@ def main():
                              + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
                              + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
-                             + ((", RCCL all-gather of 9N fp32 view-space gradient rows (equivalent to the gradient all-reduce)" if gather
+                             + ((", RCCL all-gather of 9N fp32 view-space gradient rows (equivalent to the gradient all-reduce)" if args.sync == "gather"
                                  else ", RCCL all-reduce of 59N fp32 grads") if world > 1 else "")),
                 "gaussians": N, "visible": V, "n_isects": I, "pixels": P,
                 "parallelism": f"view-parallel x{world}" if world > 1 else "single",
@@ -334,8 +430,10 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                "valu_issue": valu_issue,
+                "valu_issue": valu_issue, "counters_from": pmc_src,
             },
+            "metric_8d_fwd_bwd_grads_materialised": metric_8d,
+            "sync_modes": sync_modes, "collectives": collectives,
             "iter_byte_model": {
                 "bytes_per_iter": iter_bytes,
                 "gbps": iter_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -134,7 +134,7 @@ b9_cases = [
     (64, 96, 400, 60, 70, "lstsqrs", 4, None, False),
     (64, 96, 400, 60, 70, "ransac", 4, None, True),
     (270, 480, 3000, 61, 71, "msac", 10, None, True),
-    (270, 480, 3000, 61, 71, "ransac", "adaptive", None, False),
+    (135, 240, 1500, 64, 74, "ransac", "adaptive", None, False),
     (135, 240, 1500, 62, 72, "lstsqrs", 10, 0.05, True),
     (135, 240, 1500, 63, 73, "ransac", "adaptive", 0.1, True),
 ]
@@ -153,8 +153,9 @@ for i, (H, W, M, seed, rng_seed, aligner, factor, grad_thr, nsfm) in enumerate(b
         coords, depths = pfd.project_and_filter_sfm_pts(sc["rgb"], sc["sfm"].clone(), sc["P"], (W, H), pd, None)
         torch.manual_seed(rng_seed)
         res = DepthAlignmentPipeline.from_config(cfg).align(image, pd, coords, depths, cfg, None)
-    out[f"b9_{i}_aligned"] = res.aligned_depth[::SUB[0], ::SUB[1]].numpy()     # a lattice of the map + its sum
-    out[f"b9_{i}_aligned_sum"] = np.float64(res.aligned_depth.double().sum().item())
+    # the full map: it is the INPUT of the mask / unprojection kernels in the "identical inputs"
+    # test (an LSQ restated on another CPU differs from it in the last bit)
+    out[f"b9_{i}_aligned"] = res.aligned_depth.numpy()
     out[f"b9_{i}_align_mask"] = np.packbits(res.mask.numpy())
     # the whole chain
     pd = PredictedDepth(depth=sc["depth"].clone(), mask=sc["mask"].clone())

@@ -268,9 +268,19 @@ def test_end_to_end_small_and_predictor(N):
     M = mod("depth_prediction.predictors.metric3d")
     ifc = mod("depth_prediction.predictors.depth_predictor_interface")
     net = N.Metric3DNet(_state(SMALL_CFG), device="cuda", input_size=(112, 168), config=SMALL_CFG)
-    d, c, o = net.inference({"input": DW.image(112, 168)})
+    d, c, o = net.inference({"input": DW.image(112, 168)})       # eager pass + graph capture + replay
     _close(d[0, 0], G["dec_depth"], max_frac=4e-2, mean_frac=1e-2, what="e2e depth")
     assert torch.isfinite(o["prediction_normal"]).all()
+    # graph replay on a second image == eager on that image
+    img2 = DW.image(112, 168).flip(-1).contiguous()
+    d2, _, o2 = net.inference({"input": img2})
+    net.use_graph = False
+    d3, _, o3 = net.inference({"input": img2})
+    assert torch.equal(d2, d3) and torch.equal(o2["prediction_normal"], o3["prediction_normal"])
+    assert not torch.equal(d2, d)
+    # and through the predictor of the reference's interface (metric3d.py:38-139)
+    pred = M.Metric3d(None, "cuda", model=net, backbone="vits")
+    assert pred.name == "Metric3d_vits"
 
 
 def test_full_size_vits_runs(N):

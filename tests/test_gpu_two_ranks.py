@@ -39,14 +39,16 @@ def _setup():
     return runner, D, splats, D.fuse_optimizers(splats, opts), c2w, K, target
 
 
-def _worker_gather(rank, world, port, q):
+def _worker_gather(rank, world, port, q, chunks=3):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         runner, D, splats, fused, c2w, K, target = _setup()
-        sync = D.GatherRowsSync(fused, world, rank)
+        # 3 pipelined Gaussian ranges (boundaries on multiples of 64, the last one ragged)
+        sync = D.GatherRowsSync(fused, world, rank, chunks=chunks, min_chunk=512)
+        assert len(sync.chunk_bounds(N)) == chunks
         try:
             for step in range(3):
                 cams = [D.shard_views(6, step, r, world) for r in range(world)]
@@ -135,6 +137,20 @@ def test_two_ranks_gathered_view_space_rows_match_two_camera_batch():
     ref = _two_camera_batch_reference()
     for k in ref:
         assert torch.allclose(res[0][k], ref[k], rtol=1e-4, atol=1e-6), f"{k}: gathered rows != two-camera batch"
+
+
+def _worker_gather_monolithic(rank, world, port, q):
+    _worker_gather(rank, world, port, q, chunks=1)
+
+
+def test_pipelined_row_exchange_equals_monolithic_exchange():
+    """the exchange split into 3 Gaussian ranges (all-gather of range k+1 in
+    flight during the projection backward + Adam of range k) leaves bit-identical parameters to
+    the single all-gather + single backward launch."""
+    pipe = _run_two(_worker_gather)
+    mono = _run_two(_worker_gather_monolithic)
+    for k in pipe[0]:
+        assert torch.equal(pipe[0][k], pipe[1][k]) and torch.equal(pipe[0][k], mono[0][k]), k
 
 
 def test_two_ranks_one_gpu_pipelined_allreduce_matches_two_camera_batch():

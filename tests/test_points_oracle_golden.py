@@ -49,14 +49,18 @@ def _oracle_chain(i):
 def test_b4_pipeline_noseg(i):
     sc, co, out_depth, omask, _ = _oracle_chain(i)
     H, W = out_depth.shape
-    assert torch.equal(out_depth[::PG.SUB[0], ::PG.SUB[1]], PG.t(f"b9_{i}_aligned"))
-    assert float(out_depth.double().sum()) == pytest.approx(float(G[f"b9_{i}_aligned_sum"]), rel=1e-12)
+    # scale / shift come out of fp32 sums whose order depends on the CPU's vector width: equal on
+    # the machine that generated the fixture, within an ulp or two of the map elsewhere
+    assert torch.allclose(out_depth, PG.t(f"b9_{i}_aligned"), rtol=2e-6, atol=0)
     assert torch.equal(omask.flatten(), PG.bits(f"b9_{i}_align_mask", H * W))
 
 
 @pytest.mark.parametrize("i", range(int(G["b9_n"])))
 def test_b9_get_pts_from_depth_chain(i):
-    sc, co, out_depth, omask, (factor, grad_thr, nsfm) = _oracle_chain(i)
+    """Masks + compaction + unprojection of the oracle on the REFERENCE's aligned depth map
+    (identical inputs -> identical integer work -> bit-exact masks and points)."""
+    sc, co, _, omask, (factor, grad_thr, nsfm) = _oracle_chain(i)
+    out_depth = PG.t(f"b9_{i}_aligned")
     H, W = out_depth.shape
     sub = (IO.static_mask((H, W), factor, omask) if factor != "adaptive"
            else IO.adaptive_mask((H, W, 3), out_depth.clone(), omask))

@@ -38,6 +38,21 @@ for k, cs in pmc.items():
     for frag, entry in names.items():
         if frag in k and "SQ_INSTS_VALU" in cs:
             valu[entry] = int(cs["SQ_INSTS_VALU"])
+# one file bench.py reads, with provenance: which digest, taken at which commit
+import subprocess
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = None
+dominant = {"source": f"profiles/{tag}_pmc.json", "commit": commit, "kernels": {}}
+for k, cs in pmc.items():
+    for frag, entry in names.items():
+        if frag in k:
+            dominant["kernels"][entry] = {c: cs[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE",
+                                                           "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                           "SQ_BUSY_CYCLES") if c in cs}
+if dominant["kernels"]:
+    json.dump(dominant, open("profiles/pmc_dominant.json", "w"), indent=1, sort_keys=True)
 if traffic:        # a digest of a counter set without FETCH/WRITE must not wipe the file
     json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
 if valu:
