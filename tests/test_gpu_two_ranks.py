@@ -145,12 +145,15 @@ def _worker_gather_monolithic(rank, world, port, q):
 
 def test_pipelined_row_exchange_equals_monolithic_exchange():
     """the exchange split into 3 Gaussian ranges (all-gather of range k+1 in
-    flight during the projection backward + Adam of range k) leaves bit-identical parameters to
-    the single all-gather + single backward launch."""
+    flight during the projection backward + Adam of range k) against the single all-gather +
+    single backward launch. Replicas of one run are bit-identical (same gathered rows, same
+    per-Gaussian arithmetic); two RUNS differ in the last bits because the compositing
+    backward's float atomics land in a different order, so across runs the bar is 1e-4."""
     pipe = _run_two(_worker_gather)
     mono = _run_two(_worker_gather_monolithic)
     for k in pipe[0]:
-        assert torch.equal(pipe[0][k], pipe[1][k]) and torch.equal(pipe[0][k], mono[0][k]), k
+        assert torch.equal(pipe[0][k], pipe[1][k]) and torch.equal(mono[0][k], mono[1][k]), k
+        assert torch.allclose(pipe[0][k], mono[0][k], rtol=1e-4, atol=1e-6), k
 
 
 def test_two_ranks_one_gpu_pipelined_allreduce_matches_two_camera_batch():
