@@ -50,6 +50,9 @@ struct GemmArgs {
   float *out32;
   int ldo32;
   int act;
+  // implicit-im2col mode (CONV): A = NHWC map [cH*cW, lda], cC channels, cKS x cKS taps, stride 1
+  int cH, cW, cC, cKS, cPad;
+  const h16 *zero_page;   // >= 16 bytes of zeros
 };
 
 template <int ACT>
@@ -71,85 +74,112 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int ACT>
+// LDS image of an operand tile: [128 rows][64 halves], rows of 128 B, UNPADDED (the LDS-DMA below
+// writes wave-uniform base + lane*16, so the image must be lane-linear); the eight 16-byte chunks of
+// a row are stored XOR-swizzled, physical chunk = logical chunk ^ ((row >> 1) & 7): the 16 rows a
+// quarter-wave's ds_read_b128 touches then start in 16 distinct 4-bank groups (conflict-free). The
+// swizzle is applied on the SOURCE side: the lane that fills physical chunk p of row r fetches the
+// row's logical chunk p ^ ((r >> 1) & 7) from global memory.
+//
+// CONV: A is not a matrix in memory but the im2col view of an NHWC map (3x3 / 1x1, stride 1):
+// row m = output pixel, column k = tap * C + c. With C a multiple of 64 a 64-wide K-tile lies inside
+// one tap, so every lane's chunk is one 16-byte piece of a neighbouring pixel -- fetched straight from
+// the map (out-of-image taps and the K padding come from a zero page): no im2col buffer is written
+// or re-read.
+template <int ACT, bool CONV>
 __global__ void __launch_bounds__(256, 2)
 gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) h16 sA[2][BM * LDT];
-  __shared__ __attribute__((aligned(16))) h16 sB[2][BN * LDT];
+  __shared__ __attribute__((aligned(1024))) h16 smem[2][2][BM * BK];   // [buffer][A|B][row][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs; remap so that
+  // each XCD walks a contiguous run of tiles of the same row panel (A panel stays in its L2)
+  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
+  int wg = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
+    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+  }
+  const int m0 = (wg / nbx) * BM, n0 = (wg % nbx) * BN;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // staging map: chunk c = tid + 256*i, i = 0..3: row = (tid >> 3) + 32 i, 16-byte piece (tid & 7)
-  const int srow = tid >> 3, skc = (tid & 7) * 8;
-  const h16 *ga0 = p.A + (int64_t)min(m0 + srow, p.M - 1) * p.lda + skc;
-  const h16 *ga1 = p.A + (int64_t)min(m0 + srow + 32, p.M - 1) * p.lda + skc;
-  const h16 *ga2 = p.A + (int64_t)min(m0 + srow + 64, p.M - 1) * p.lda + skc;
-  const h16 *ga3 = p.A + (int64_t)min(m0 + srow + 96, p.M - 1) * p.lda + skc;
-  const h16 *gb0 = p.W + (int64_t)min(n0 + srow, p.N - 1) * p.K + skc;
-  const h16 *gb1 = p.W + (int64_t)min(n0 + srow + 32, p.N - 1) * p.K + skc;
-  const h16 *gb2 = p.W + (int64_t)min(n0 + srow + 64, p.N - 1) * p.K + skc;
-  const h16 *gb3 = p.W + (int64_t)min(n0 + srow + 96, p.N - 1) * p.K + skc;
-  const int so = srow * LDT + skc;
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define DN_GLOAD(k0)                                                  \
-  ra0 = *reinterpret_cast<const uint4 *>(ga0 + (k0));                 \
-  ra1 = *reinterpret_cast<const uint4 *>(ga1 + (k0));                 \
-  ra2 = *reinterpret_cast<const uint4 *>(ga2 + (k0));                 \
-  ra3 = *reinterpret_cast<const uint4 *>(ga3 + (k0));                 \
-  rb0 = *reinterpret_cast<const uint4 *>(gb0 + (k0));                 \
-  rb1 = *reinterpret_cast<const uint4 *>(gb1 + (k0));                 \
-  rb2 = *reinterpret_cast<const uint4 *>(gb2 + (k0));                 \
-  rb3 = *reinterpret_cast<const uint4 *>(gb3 + (k0));
-#define DN_SSTORE(buf)                                                         \
-  *reinterpret_cast<uint4 *>(&sA[buf][so]) = ra0;                              \
-  *reinterpret_cast<uint4 *>(&sA[buf][so + 32 * LDT]) = ra1;                   \
-  *reinterpret_cast<uint4 *>(&sA[buf][so + 64 * LDT]) = ra2;                   \
-  *reinterpret_cast<uint4 *>(&sA[buf][so + 96 * LDT]) = ra3;                   \
-  *reinterpret_cast<uint4 *>(&sB[buf][so]) = rb0;                              \
-  *reinterpret_cast<uint4 *>(&sB[buf][so + 32 * LDT]) = rb1;                   \
-  *reinterpret_cast<uint4 *>(&sB[buf][so + 64 * LDT]) = rb2;                   \
-  *reinterpret_cast<uint4 *>(&sB[buf][so + 96 * LDT]) = rb3;
+  // staging: wave w, instruction i moves rows (4w + i)*8 .. +7; lane -> (row, physical chunk)
+  const int srow = lane >> 3, pch = lane & 7;
+  const h16 *ga[4], *gb[4];
+  int pix_y[4], pix_x[4], lch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + srow;
+    lch[i] = (pch ^ ((r >> 1) & 7)) * 8;                 // logical chunk offset in halves
+    const int m = min(m0 + r, p.M - 1);
+    if (CONV) {
+      pix_y[i] = m / p.cW;
+      pix_x[i] = m - pix_y[i] * p.cW;
+      ga[i] = nullptr;
+    } else {
+      ga[i] = p.A + (int64_t)m * p.lda + lch[i];
+    }
+    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto stage = [&](int buf, int k0) {
+    int ky = 0, kx = 0, c0 = 0;
+    bool tap_ok = true;
+    if (CONV) {
+      const int tap = k0 / p.cC;                          // wave-uniform
+      c0 = k0 - tap * p.cC;
+      ky = tap / p.cKS;
+      kx = tap - ky * p.cKS;
+      tap_ok = tap < p.cKS * p.cKS;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const h16 *src;
+      if (CONV) {
+        const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
+        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
+      } else {
+        src = ga[i] + k0;
+      }
+      h16 *dA = &smem[buf][0][(wave * 4 + i) * 8 * BK];
+      h16 *dB = &smem[buf][1][(wave * 4 + i) * 8 * BK];
+      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dA, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + k0), (lds_void *)dB, 16, 0, 0);
+    }
+  };
 
   f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
 
+  // fragment rows of this lane and their swizzle terms
+  const int ra0 = wm * 64 + lr, ra1 = ra0 + 32, rb0 = wn * 64 + lr, rb1 = rb0 + 32;
+  const int xa0 = (ra0 >> 1) & 7, xa1 = (ra1 >> 1) & 7, xb0 = (rb0 >> 1) & 7, xb1 = (rb1 >> 1) & 7;
+
   const int nk = p.K / BK;
-  DN_GLOAD(0)
-  DN_SSTORE(0)
-  __syncthreads();
+  stage(0, 0);
+  __syncthreads();            // (drains the LDS-DMA: the barrier's fence waits vmcnt(0))
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      DN_GLOAD((kt + 1) * BK)
-    }
-    const h16 *a_base = &sA[buf][(wm * 64 + lr) * LDT + lh * 8];
-    const h16 *b_base = &sB[buf][(wn * 64 + lr) * LDT + lh * 8];
+    if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
+    const h16 *sA = smem[buf][0], *sB = smem[buf][1];
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      const half8 af0 = *reinterpret_cast<const half8 *>(a_base + s * 16);
-      const half8 af1 = *reinterpret_cast<const half8 *>(a_base + 32 * LDT + s * 16);
-      const half8 bf0 = *reinterpret_cast<const half8 *>(b_base + s * 16);
-      const half8 bf1 = *reinterpret_cast<const half8 *>(b_base + 32 * LDT + s * 16);
+      const int cl = 2 * s + lh;
+      const half8 af0 = *reinterpret_cast<const half8 *>(sA + ra0 * BK + ((cl ^ xa0) << 3));
+      const half8 af1 = *reinterpret_cast<const half8 *>(sA + ra1 * BK + ((cl ^ xa1) << 3));
+      const half8 bf0 = *reinterpret_cast<const half8 *>(sB + rb0 * BK + ((cl ^ xb0) << 3));
+      const half8 bf1 = *reinterpret_cast<const half8 *>(sB + rb1 * BK + ((cl ^ xb1) << 3));
       acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf0, acc00, 0, 0, 0);
       acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc01, 0, 0, 0);
       acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc11, 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-      if (buf == 0) {
-        DN_SSTORE(1)
-      } else {
-        DN_SSTORE(0)
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
+    __syncthreads();          // tile kt+1 has landed, and every wave is done reading tile kt
+    buf ^= 1;
   }
-#undef DN_GLOAD
-#undef DN_SSTORE
 
   // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
   auto emit = [&](const f32x16 &acc, int i, int j) {
@@ -630,6 +660,21 @@ static inline unsigned grid_for(int64_t total) {
 
 using namespace gsr::dn;
 
+template <bool CONV>
+static int launch_gemm(const GemmArgs &p, void *stream) {
+  dim3 grid((unsigned)gsr::ceil_div(p.N, gsr::dn::BN), (unsigned)gsr::ceil_div(p.M, gsr::dn::BM));
+  hipStream_t st = (hipStream_t)stream;
+  switch (p.act) {
+    case ACT_GELU: hipLaunchKernelGGL((gemm_kernel<ACT_GELU, CONV>), grid, dim3(256), 0, st, p); break;
+    case ACT_RELU: hipLaunchKernelGGL((gemm_kernel<ACT_RELU, CONV>), grid, dim3(256), 0, st, p); break;
+    case ACT_SIGMOID: hipLaunchKernelGGL((gemm_kernel<ACT_SIGMOID, CONV>), grid, dim3(256), 0, st, p); break;
+    case ACT_TANH: hipLaunchKernelGGL((gemm_kernel<ACT_TANH, CONV>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_kernel<ACT_NONE, CONV>), grid, dim3(256), 0, st, p); break;
+  }
+  GSR_CHECK_LAUNCH("dn_gemm");
+  return GSR_OK;
+}
+
 extern "C" int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W,
                            const float *bias, int act, const float *gamma, const float *residual,
                            int ldr, const void *residual16, int ldr16, void *out16, int ldo16,
@@ -638,24 +683,39 @@ extern "C" int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const vo
   if (M == 0 || N == 0) return GSR_OK;
   GSR_REQUIRE(A && W && (out16 || out32), "dn_gemm: null pointer");
   GSR_REQUIRE(lda >= K && (lda % 8) == 0, "dn_gemm: lda %d (>= K, multiple of 8 halves)", lda);
+  GSR_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "dn_gemm: A and W must be 16-byte aligned");
   GSR_REQUIRE(act >= 0 && act <= 4, "dn_gemm: act %d", act);
-  GemmArgs p;
+  GemmArgs p = {};
   p.M = M; p.N = N; p.K = K;
   p.A = (const h16 *)A; p.lda = lda; p.W = (const h16 *)W;
   p.bias = bias; p.gamma = gamma; p.residual = residual; p.ldr = ldr;
   p.residual16 = (const h16 *)residual16; p.ldr16 = ldr16;
   p.out16 = (h16 *)out16; p.ldo16 = ldo16; p.out32 = out32; p.ldo32 = ldo32;
   p.act = act;
-  dim3 grid((unsigned)gsr::ceil_div(N, gsr::dn::BN), (unsigned)gsr::ceil_div(M, gsr::dn::BM));
-  switch (act) {
-    case ACT_GELU: hipLaunchKernelGGL(gemm_kernel<ACT_GELU>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-    case ACT_RELU: hipLaunchKernelGGL(gemm_kernel<ACT_RELU>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-    case ACT_SIGMOID: hipLaunchKernelGGL(gemm_kernel<ACT_SIGMOID>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-    case ACT_TANH: hipLaunchKernelGGL(gemm_kernel<ACT_TANH>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-    default: hipLaunchKernelGGL(gemm_kernel<ACT_NONE>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-  }
-  GSR_CHECK_LAUNCH("dn_gemm");
-  return GSR_OK;
+  return launch_gemm<false>(p, stream);
+}
+
+extern "C" int gsr_dn_conv_gemm(int H, int Wd, int C, const void *in, int ldi, int KS, int N, int K_pad,
+                                const void *W, const float *bias, int act, const void *residual16,
+                                int ldr16, void *out16, int ldo16, const void *zero_page, void *stream) {
+  GSR_REQUIRE(H > 0 && Wd > 0 && C > 0 && C % 64 == 0 && (KS == 1 || KS == 3) && N > 0 &&
+                  K_pad >= KS * KS * C && K_pad % gsr::dn::BK == 0,
+              "dn_conv_gemm: bad sizes H=%d W=%d C=%d (C %% 64) KS=%d K_pad=%d", H, Wd, C, KS, K_pad);
+  GSR_REQUIRE(in && W && out16 && zero_page, "dn_conv_gemm: null pointer");
+  GSR_REQUIRE((ldi % 8) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+                  ((uintptr_t)zero_page & 15) == 0,
+              "dn_conv_gemm: 16-byte alignment of the map, the weights and the zero page");
+  GSR_REQUIRE(act >= 0 && act <= 4, "dn_conv_gemm: act %d", act);
+  GemmArgs p = {};
+  p.M = H * Wd; p.N = N; p.K = K_pad;
+  p.A = (const h16 *)in; p.lda = ldi; p.W = (const h16 *)W;
+  p.bias = bias;
+  p.residual16 = (const h16 *)residual16; p.ldr16 = ldr16;
+  p.out16 = (h16 *)out16; p.ldo16 = ldo16;
+  p.act = act;
+  p.cH = H; p.cW = Wd; p.cC = C; p.cKS = KS; p.cPad = KS / 2;
+  p.zero_page = (const h16 *)zero_page;
+  return launch_gemm<true>(p, stream);
 }
 
 extern "C" int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,

@@ -80,7 +80,10 @@ class Map:
     def __init__(self, H, W, C, device, ld=None, t=None):
         self.H, self.W, self.C = H, W, C
         self.ld = ld if ld is not None else _ceil(C, 8)
-        self.t = t if t is not None else torch.zeros(H * W, self.ld, dtype=torch.float16, device=device)
+        if t is None:    # padding channels must hold finite values (they meet zero weights in a GEMM)
+            alloc = torch.empty if self.ld == C else torch.zeros
+            t = alloc(H * W, self.ld, dtype=torch.float16, device=device)
+        self.t = t
 
     @property
     def P(self):
@@ -217,10 +220,21 @@ class Metric3DNet:
 
     def conv(self, x: Map, lin: _Lin, ks: int, out: Map, act=ACT_NONE, relu_in=False, stride=1,
              residual: Optional[Map] = None):
-        """out[:, :N] = act(conv_ks(x) + b) (+ residual). 1x1 convolutions read x directly."""
+        """out[:, :N] = act(conv_ks(x) + b) (+ residual), stride-1 "same" convolution.
+        C % 64 == 0: implicit GEMM (`gsr_dn_conv_gemm` gathers the taps straight from the map);
+        otherwise im2col rows + `gsr_dn_gemm` (the 6-channel flow concatenations, small configs)."""
         pad = ks // 2
         Ho, Wo = (x.H + 2 * pad - ks) // stride + 1, (x.W + 2 * pad - ks) // stride + 1
         assert (Ho, Wo) == (out.H, out.W) and lin.k == ks * ks * x.C, (lin.k, ks, x.C)
+        if x.C % 64 == 0 and stride == 1 and not relu_in and x.t.data_ptr() % 16 == 0:
+            if getattr(self, "flop_count", None) is not None:
+                self.flop_count += 2.0 * Ho * Wo * lin.n * lin.k
+            if getattr(self, "_zero_page", None) is None:
+                self._zero_page = torch.zeros(64, dtype=torch.float16, device=self.dev)
+            call("gsr_dn_conv_gemm", x.H, x.W, x.C, ptr(x.t), x.ld, ks, lin.n, lin.kp, ptr(lin.w), ptr(lin.b), act,
+                 None if residual is None else ptr(residual.t), 0 if residual is None else residual.ld,
+                 ptr(out.t), out.ld, ptr(self._zero_page), _st())
+            return out
         if ks == 1 and not relu_in and x.ld >= lin.kp and x.C == lin.k and lin.kp == lin.k:
             A, lda = x.t, x.ld
         else:
@@ -304,8 +318,8 @@ class Metric3DNet:
         input rectified for every later reader -- the context encoder sees relu'd 1/14 and 1/7
         features (decoder :911-919 after :899). Reproduced, side effect included."""
         self.copy(x, x, act=ACT_RELU)
-        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev))
-        return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev), relu_in=True, residual=x)
+        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev), act=ACT_RELU)     # relu(conv1(.)) in the epilogue
+        return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev), residual=x)
 
     def _fuse(self, name, x1: Map, x2: Optional[Map], size) -> Map:
         """FuseBlock (decoder :550-588). The 1x1 out_conv commutes with the bilinear upsampling
@@ -321,8 +335,10 @@ class Metric3DNet:
             o = self.resize(o, size[0], size[1], RESIZE_BILINEAR_AC)
         return o
 
-    def _residual_block(self, x: Map, rb) -> Map:
-        """ResidualBlock with LayerNorm2d + the trailing 3x3 conv (ContextFeatureEncoder, :412-517)."""
+    def _residual_block(self, x: Map, rb, act=ACT_NONE) -> Map:
+        """ResidualBlock with LayerNorm2d + the trailing 3x3 conv (ContextFeatureEncoder, :412-517);
+        `act` = what the caller applies to the result (tanh: hidden state, ReLU: context), fused
+        into the trailing convolution's epilogue."""
         C = rb["c1"].n
         y = self.conv(x, rb["c1"], 3, Map(x.H, x.W, C, self.dev))
         self.layernorm2d(y, rb["norm1"], relu=True)
@@ -334,7 +350,7 @@ class Metric3DNet:
         else:
             xs = x
         self.copy(xs, y, accumulate=True, act=ACT_RELU)              # relu(x + y)
-        return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev))
+        return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev), act=act)
 
     def _gru(self, g, h: Map, ctx: Map, xs: List[Map]):
         """ConvGRU.forward (decoder :318-330); h is updated in place."""
@@ -411,10 +427,9 @@ class Metric3DNet:
         # context encoder (:919-921) on (x_4, x_8, x_16) = (x0, x1, x2)
         nets, ctxs = [], []
         for lvl, src, zq in (("04", x0, self.zqr[0]), ("08", x1, self.zqr[1]), ("16", x2, self.zqr[2])):
-            hnet = self._residual_block(src, self.ctx[lvl][0])
-            self.copy(hnet, hnet, act=ACT_TANH)                               # net = tanh(.)
-            c = self._residual_block(src, self.ctx[lvl][1])
-            ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev), relu_in=True)  # zqr(relu(.)) -> [cz|cr|cq]
+            hnet = self._residual_block(src, self.ctx[lvl][0], act=ACT_TANH)   # net = tanh(.)
+            c = self._residual_block(src, self.ctx[lvl][1], act=ACT_RELU)      # inp = relu(.)
+            ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev))                # zqr(.) -> [cz|cr|cq]
             nets.append(hnet)
             ctxs.append(ctx)
         if return_intermediates:

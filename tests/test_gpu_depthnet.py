@@ -113,15 +113,24 @@ def test_layernorm_conv_resize_pool_vs_torch(N):
     # 3x3 convolution through im2col + GEMM, stride 1 and C not a multiple of 8
     net = N.Metric3DNet.__new__(N.Metric3DNet)
     net.dev, net._scratch = torch.device("cuda"), {}
-    for C, Co, H, W in ((38, 16, 28, 42), (64, 96, 44, 76)):
+    # (C % 64 == 0 without input ReLU takes the implicit-GEMM path, everything else im2col rows)
+    for C, Co, H, W, ks, relu_in in ((38, 16, 28, 42, 3, True), (64, 96, 44, 76, 3, True), (64, 96, 44, 76, 3, False),
+                                     (128, 258, 31, 45, 3, False), (192, 48, 17, 23, 1, False)):
         xin = torch.randn(1, C, H, W, generator=g)
-        wt = torch.randn(Co, C, 3, 3, generator=g) / (9 * C) ** 0.5
+        wt = torch.randn(Co, C, ks, ks, generator=g) / (ks * ks * C) ** 0.5
         bs = torch.randn(Co, generator=g)
         m = N.Map(H, W, C, "cuda")
         m.t[:, :C] = xin[0].permute(1, 2, 0).reshape(-1, C).half().cuda()
-        out = net.conv(m, N._conv_lin(wt, bs, "cuda"), 3, N.Map(H, W, Co, "cuda"), act=N.ACT_RELU, relu_in=True)
-        ref = F.relu(F.conv2d(F.relu(xin.half().float()), wt.half().float(), bs, padding=1))[0].permute(1, 2, 0)
-        assert float((out.t[:, :Co].float().cpu().view(H, W, Co) - ref).abs().max()) <= 3e-3 * float(ref.abs().max())
+        res = N.Map(H, W, Co, "cuda")
+        res.t.zero_()
+        rin = torch.randn(H * W, Co, generator=g).half()
+        res.t[:, :Co] = rin.cuda()
+        out = net.conv(m, N._conv_lin(wt, bs, "cuda"), ks, N.Map(H, W, Co, "cuda"), act=N.ACT_RELU, relu_in=relu_in,
+                       residual=res)
+        a = F.relu(xin.half().float()) if relu_in else xin.half().float()
+        ref = F.relu(F.conv2d(a, wt.half().float(), bs, padding=ks // 2))[0].permute(1, 2, 0) + rin.float().view(H, W, Co)
+        err = float((out.t[:, :Co].float().cpu().view(H, W, Co) - ref).abs().max())
+        assert err <= 3e-3 * float(ref.abs().max()), (C, Co, ks, relu_in, err)
     # resize modes and pooling
     xin = torch.randn(1, 16, 11, 13, generator=g).half()
     m = N.Map(11, 13, 16, "cuda")

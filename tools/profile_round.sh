@@ -1,16 +1,21 @@
 #!/bin/bash
-# Collect the round's evidence on the GPU box: rocprofv3 kernel stats of bench.py and the
-# FETCH_SIZE / WRITE_SIZE PMC passes (separate passes, as MI355X_MICROARCH.md prescribes).
+# Collect the round's evidence on the GPU box: rocprofv3 kernel stats of bench.py (and of the depth
+# network) and the PMC passes (separate passes, counters only with --kernel-trace, as
+# MI355X_MICROARCH.md prescribes). Digest afterwards in the build container:
+#   python tools/digest_profiles.py <tag>
 # Usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1 || exit 1
+echo "stats done"
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum"; do
   D=$R/gpurun_out/${TAG}_pmc_$(echo $P | cut -d" " -f1)
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d $D -- python3 $R/tools/prof_step.py > $D.log 2>&1 || exit 1
+  echo "pmc $P done"
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_dn_stats -- python3 $R/tools/bench_depthnet.py --backbones vitl --iters 3 > $R/gpurun_out/${TAG}_dn_stats.log 2>&1 || exit 1
 echo "profile_round done"
