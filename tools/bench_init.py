@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--aligner", default="ransac")
     ap.add_argument("--subsample", default="10")
     ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--network", default="vits", choices=("vits", "vitl", "none"),
+                    help="c3's depth predictor (Metric3D on MFMA, deterministic random weights) timed per "
+                         "image at 1080p incl. its pre/post-processing; the alignment chain runs on the "
+                         "synthetic depth (random weights predict nothing alignable)")
     args = ap.parse_args()
     H, W = 1080, 1920
     pkg = "3dgs_monocular_depth_init_amd."
@@ -78,6 +82,23 @@ def main():
             n += pts.shape[0]
         torch.cuda.synchronize()
         return n
+
+    net_ms = None
+    if args.network != "none":
+        M3 = importlib.import_module(pkg + "depth_prediction.predictors.metric3d")
+        NET = importlib.import_module(pkg + "depth_prediction.predictors.metric3d_net")
+        from tests import test_gpu_depthnet as T
+        net = NET.Metric3DNet(T._state(NET.CONFIGS[args.network]), backbone=args.network, device="cuda")
+        pred = M3.Metric3d(None, "cuda", model=net, backbone=args.network)
+        intr = dpi.CameraIntrinsics(scenes_[0][2])
+        pred.predict_depth(dev[0][1].data, intr)        # warm-up: eager pass + graph capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _, image, _ in dev:
+            out = pred.predict_depth(image.data, dpi.CameraIntrinsics(image.K))
+        torch.cuda.synchronize()
+        net_ms = 1e3 * (time.perf_counter() - t0) / len(dev)
+        assert out.depth.shape == (H, W) and bool(torch.isfinite(out.depth).all())
 
     torch.manual_seed(42)
     gpu_pass()                                     # warm-up
@@ -109,6 +130,10 @@ def main():
                   % (args.aligner, args.subsample),
         "value": args.images / dt_gpu, "unit": "images/s", "images": args.images, "seed_points": n_pts,
         "ms_per_image": 1e3 * dt_gpu / args.images,
+        "depth_network": None if net_ms is None else {
+            "model": f"Metric3D-{args.network} (fp16 MFMA, random weights)", "ms_per_image": net_ms,
+            "includes": "1080p -> 616x1064 letterbox, network, un-pad + upsample + de-canonicalise"},
+        "ms_per_image_with_network": None if net_ms is None else net_ms + 1e3 * dt_gpu / args.images,
         "algorithmic_bytes_per_image": per_img, "gbps": per_img * args.images / dt_gpu / 1e9,
         "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "images/s", "kind": "port",
                          "cores": torch.get_num_threads(), "sample": f"{args.cpu_images} images"},
