@@ -90,6 +90,11 @@ SIGNATURES.update({
     "gsr_dn_convex_upsample": [_i, _i, _i, _p, _p, _i, _f, _f, _f, _p, _p, _p, _p],
     "gsr_dn_cvt_f32_f16": [_i64, _i, _p, _i, _p, _i, _p],
 })
+SIGNATURES.update({
+    "gsr_pc_min_extents": [_i, _i, _p, _p, _p, _p, _p, _p],
+    "gsr_pc_subsample_workspace_bytes": [_i],          # returns int64 bytes (restype set in load())
+    "gsr_pc_subsample": [_i, _p, _p, _p, _f, _f, _p, _i64, _p, _p, _p, _p],
+})
 OPTIONAL_SIGNATURES: dict = {}   # filled by modules that add entry points (init path, train ops)
 
 
@@ -122,6 +127,7 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = args
             fn.restype = C.c_int
+        lib.gsr_pc_subsample_workspace_bytes.restype = C.c_int64
         _lib = lib
         return lib
 

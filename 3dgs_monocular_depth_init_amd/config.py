@@ -7,6 +7,7 @@ from typing import Literal, Optional, Union
 
 from .depth_alignment.config import DepthAlignmentConfig
 from .depth_subsampling.config import AdaptiveSubsamplingConfig, NumSfMPointsMaskConfig
+from .point_cloud_postprocess.config import PointCloudPostprocessConfig
 
 
 class Metric3dBackbone(str, Enum):          # depth_prediction/configs.py:33-36
@@ -30,6 +31,7 @@ class MonocularDepthInitConfig:
     adaptive_subsampling: AdaptiveSubsamplingConfig = field(default_factory=AdaptiveSubsamplingConfig)
     use_num_sfm_points_mask: bool = True
     num_sfm_points_mask: NumSfMPointsMaskConfig = field(default_factory=NumSfMPointsMaskConfig)
+    postprocess: PointCloudPostprocessConfig = field(default_factory=PointCloudPostprocessConfig)
     limit_init_scale: bool = False
     init_scale_clamp_quantile: float = 0.75
     noise_std_scene_frac: Optional[float] = None

@@ -79,9 +79,13 @@ def add_noise_to_point_cloud(pts: torch.Tensor, noise_std: float):      # monocu
     return pts + torch.randn_like(pts) * noise_std
 
 
-def _finish(config, points_list, rgbs_list, device):
+def _finish(config, points_list, rgbs_list, device, cams=None):
     pts = torch.cat(points_list, dim=0).float()
     rgbs = torch.cat(rgbs_list, dim=0).float()
+    pp = getattr(config.mdi, "postprocess", None)
+    if pp is not None and cams is not None and (pp.subsample or pp.outlier_removal.value != "none"):
+        from .point_cloud_postprocess.postprocess import postprocess_point_cloud      # :187-196
+        pts, rgbs = postprocess_point_cloud(pts, rgbs, cams[0], cams[1], cams[2], pp, device)
     scales = None
     if config.mdi.limit_init_scale:                                     # :215-223
         from .knn import knn
@@ -106,6 +110,7 @@ def pts_and_rgb_from_monocular_depth(config, parser, device: str = "cuda", model
     rgbs_list: List[torch.Tensor] = []
     dataset = type(parser).DatasetCls(parser, split="train")
     use_cache = getattr(config.mdi, "cache_dir", None) is not None
+    intrinsic_matrices, proj_matrices, image_sizes = [], [], []
     for data in dataset:
         assert data["image"].max() > 1                                  # :122 images are 0-255
         image = InputImage(name=data["image_name"], cam2world=data["camtoworld"], K=data["K"],
@@ -128,10 +133,13 @@ def pts_and_rgb_from_monocular_depth(config, parser, device: str = "cuda", model
                 points, parser.scene_scale * config.mdi.noise_std_scene_frac)
         points_list.append(points)
         rgbs_list.append(rgbs.float())
+        intrinsic_matrices.append(image.K.cpu().numpy())                # :170-172
+        proj_matrices.append(P.cpu().numpy())
+        image_sizes.append(np.array(image.data.shape[:2][::-1], dtype=np.int32))
     if config.mdi.include_sfm_points:                                   # :179-181
         points_list.append(torch.from_numpy(np.asarray(parser.points)).float().to(device))
         rgbs_list.append(torch.from_numpy(np.asarray(parser.points_rgb) / 255.0).float().to(device))
-    return _finish(config, points_list, rgbs_list, device)
+    return _finish(config, points_list, rgbs_list, device, (intrinsic_matrices, proj_matrices, image_sizes))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -486,6 +486,25 @@ int gsr_dn_convex_upsample(int H, int W, int F, const float *flow, const void *m
                            float *conf, float *normal, void *stream);
 int gsr_dn_cvt_f32_f16(int64_t P, int C, const float *in, int ldi, void *out, int ldo, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * F4: the reference's native point-cloud subsampler (native_modules/subsampling, C++/Eigen,
+ * pybind `_pointcloud_subsampling.subsample_pointcloud`, pointcloud_subsampling.cpp:22-67).
+ * --------------------------------------------------------------------------*/
+/* compute_minimal_gaussian_extents (impl.cpp:70-126): extents[i] = min over the cameras that see
+ * point i of 2*depth/min(fx,fy); -1 when none does. Ks [C,3,3], Ps [C,3,4] (K R [I|-C]),
+ * image_sizes [C,2] = (width, height). */
+int gsr_pc_min_extents(int N, int C, const float *points, const float *Ks, const float *Ps,
+                       const int32_t *image_sizes, float *extents, void *stream);
+/* subsample_pointcloud_impl (impl.cpp:313-426): spatial-median tree over the points' bounding cube,
+ * nodes merged into their mean when compact enough. Outputs are written in tree (bit-path) order:
+ * out_points / out_rgbs [<= N,3], *out_count on the device. workspace: device scratch of at least
+ * gsr_pc_subsample_workspace_bytes(N) bytes (returns -1 for N < 0). */
+int64_t gsr_pc_subsample_workspace_bytes(int N);
+int gsr_pc_subsample(int N, const float *points, const float *rgbs, const float *extents,
+                     float max_bbox_aspect_ratio, float min_extent_multiplier, void *workspace,
+                     int64_t workspace_bytes, float *out_points, float *out_rgbs, int32_t *out_count,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif
