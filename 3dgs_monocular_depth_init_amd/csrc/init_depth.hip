@@ -542,3 +542,48 @@ extern "C" int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_
   GSR_CHECK_LAUNCH("m3d_postprocess");
   return GSR_OK;
 }
+
+// ---- F4 (tail): piecewise-linear interpolation over a Delaunay triangulation ------------------
+// Replaces scipy.interpolate.LinearNDInterpolator(dt, values)(X, Y) on the full pixel grid
+// (depth_alignment/alignment/interp.py:77-110: ~2 M queries on the CPU in the reference). The
+// triangulation itself (a few thousand SfM points) stays a host call to scipy, as in the
+// reference; here one thread block per triangle walks the integer pixels of its bounding box
+// and writes the barycentric interpolation (fp64, like scipy) for those inside or on the edge.
+// Pixels on a shared edge are written by both neighbours with values equal to rounding.
+namespace gsr {
+__global__ void __launch_bounds__(64)
+tri_interp_kernel(int H, int W, int n_tri, const double *__restrict__ xy, const int32_t *__restrict__ tris,
+                  const double *__restrict__ values, float *__restrict__ out) {
+  const int t = blockIdx.x;
+  if (t >= n_tri) return;
+  const int i0 = tris[t * 3], i1 = tris[t * 3 + 1], i2 = tris[t * 3 + 2];
+  const double x0 = xy[i0 * 2], y0 = xy[i0 * 2 + 1], x1 = xy[i1 * 2], y1 = xy[i1 * 2 + 1];
+  const double x2 = xy[i2 * 2], y2 = xy[i2 * 2 + 1];
+  const double det = (y1 - y2) * (x0 - x2) + (x2 - x1) * (y0 - y2);
+  if (det == 0.0) return;                                  // degenerate (collinear) simplex
+  const double v0 = values[i0], v1 = values[i1], v2 = values[i2];
+  const int bx0 = max(0, (int)ceil(fmin(x0, fmin(x1, x2)))), bx1 = min(W - 1, (int)floor(fmax(x0, fmax(x1, x2))));
+  const int by0 = max(0, (int)ceil(fmin(y0, fmin(y1, y2)))), by1 = min(H - 1, (int)floor(fmax(y0, fmax(y1, y2))));
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  if (bw <= 0 || bh <= 0) return;
+  const double eps = 1e-10;
+  for (int k = threadIdx.x; k < bw * bh; k += blockDim.x) {
+    const int px = bx0 + k % bw, py = by0 + k / bw;
+    const double l0 = ((y1 - y2) * (px - x2) + (x2 - x1) * (py - y2)) / det;
+    const double l1 = ((y2 - y0) * (px - x2) + (x0 - x2) * (py - y2)) / det;
+    const double l2 = 1.0 - l0 - l1;
+    if (l0 >= -eps && l1 >= -eps && l2 >= -eps) out[(int64_t)py * W + px] = (float)(l0 * v0 + l1 * v1 + l2 * v2);
+  }
+}
+}  // namespace gsr
+
+extern "C" int gsr_tri_interp(int H, int W, int n_tri, const double *xy, const int32_t *tris,
+                              const double *values, float *out, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && n_tri >= 0, "tri_interp: bad sizes");
+  if (n_tri == 0) return GSR_OK;
+  GSR_REQUIRE(xy && tris && values && out, "tri_interp: null pointer");
+  hipLaunchKernelGGL(gsr::tri_interp_kernel, dim3((unsigned)n_tri), dim3(64), 0, (hipStream_t)stream, H, W,
+                     n_tri, xy, tris, values, out);
+  GSR_CHECK_LAUNCH("tri_interp");
+  return GSR_OK;
+}

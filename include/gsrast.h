@@ -371,6 +371,12 @@ int gsr_subsample_mask(int H, int W, int mode, int static_k, const float *depth,
  * the pixel's patch holds > threshold points. */
 int gsr_sfm_patch_mask(int H, int W, int M, const int64_t *coords, int ph, int pw, int gh,
                        int gw, int threshold, int32_t *patch_counts, uint8_t *mask, void *stream);
+/* F4 tail (depth_alignment/alignment/interp.py:77-110): scipy's LinearNDInterpolator evaluated on
+ * the integer pixel grid: xy fp64 [P,2] vertex coordinates (x, y), tris int32 [n_tri,3] (scipy's
+ * Delaunay simplices), values fp64 [P]; writes out[y*W + x] for every pixel inside a triangle
+ * (`out` should be pre-filled with the fill value). */
+int gsr_tri_interp(int H, int W, int n_tri, const double *xy, const int32_t *tris, const double *values,
+                   float *out, void *stream);
 /* B8 (points_from_depth.py:203-208): |dx| + |dy| backward differences. */
 int gsr_depth_grad(int H, int W, const float *depth, float *grad, void *stream);
 /* B9 (points_from_depth.py:270-312): fused mask -> ordered stream compaction ->
