@@ -10,10 +10,10 @@ hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize --save-temps "$ROOT/tools/ube
 S=valu_rate-hip-amdgcn-amd-amdhsa-gfx950.s
 # VALU instructions in the innermost loop of every mode, from the ISA
 ARGS=""
-for M in 0 1 2 3 4 5 6 7 8; do
+for M in 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15; do
   C=$(python3 "$ROOT/tools/isa_hist.py" "$S" --kernel "Li${M}E" --json | python3 -c 'import json,sys; d=json.load(sys.stdin); k=next(iter(d.values())); print(max(l["valu_total"] for l in k["loops"] if l["innermost"]))')
   ARGS="$ARGS $C"
 done
-echo "VALU instructions per trip, modes 0..8:$ARGS" >&2
+echo "VALU instructions per trip, modes 0..15:$ARGS" >&2
 ./valu_rate $ARGS | tee "$OUT/valu_rate.jsonl"
 python3 "$ROOT/tools/isa_hist.py" "$S" > "$OUT/valu_rate_isa.txt"

@@ -40,10 +40,19 @@ enum Mode {
   PK_CHAIN,        // 8 v_pk_fma_f32 in one dependent chain
   COMPOSITE1,      // the compositing body's shape: sigma -> exp -> alpha -> T chain, one Gaussian
   COMPOSITE2,      // the same, two Gaussians per trip (two independent sigma/exp/alpha chains)
+  RCP_ALL,         // 16 v_rcp_f32 (transcendental pipe alone)
+  PERMLANE32,      // 8 x (v_permlane32_swap + v_add): the backward's halving-tree step
+  PERMLANE16,      // 8 x (v_permlane16_swap + v_add)
+  DPP_ROW,         // 16 x v_add_f32 row_ror:4 (DPP, full rate?)
+  DPP_BCAST,       // 8 x (row_bcast:15 + row_bcast:31 adds, with their s_nop)
+  READFIRST,       // 16 x (v_readfirstlane + s_add dependent on it)
+  CMP_E64_CND,     // 16 x (v_cmp_gt_f32_e64 s[..] ; v_cndmask_b32_e64 with that SGPR pair)
   N_MODES
 };
 static const char *kName[N_MODES] = {"indep_fma", "chain1",   "chain2",     "mul_cmp_cnd", "exp_quarter",
-                                     "pk_fma",    "pk_chain", "composite1", "composite2"};
+                                     "pk_fma",    "pk_chain", "composite1", "composite2",  "rcp_all",
+                                     "permlane32_swap_add", "permlane16_swap_add", "dpp_row_ror_add",
+                                     "dpp_bcast_add", "readfirstlane_salu", "cmp_e64_cndmask"};
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *stamps, int iters, float a_,
@@ -80,6 +89,44 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *stamps
         acc2 = __builtin_fmaf(w, r[14], acc2);
         T = T - w;
         r[0 + g] += 1e-7f;  // the next Gaussian's parameters differ
+      }
+    } else if constexpr (MODE == RCP_ALL) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = __builtin_amdgcn_rcpf(r[i]);
+    } else if constexpr (MODE == PERMLANE32 || MODE == PERMLANE16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        auto v = MODE == PERMLANE32
+                     ? __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]), false, false)
+                     : __builtin_amdgcn_permlane16_swap(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]), false, false);
+        const unsigned v0 = v[0], v1 = v[1];
+        r[2 * i] = __uint_as_float(v0) + __uint_as_float(v1);
+      }
+    } else if constexpr (MODE == DPP_ROW) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[i]), 0x124, 0xf, 0xf, false);
+        r[i] += __builtin_bit_cast(float, m);
+      }
+    } else if constexpr (MODE == DPP_BCAST) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(r[i]));
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(r[i]));
+      }
+    } else if constexpr (MODE == READFIRST) {
+      int acc_s = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc_s += __builtin_amdgcn_readfirstlane(__float_as_int(r[i])) & 0xff;
+        r[i] += 1e-7f;
+      }
+      if (acc_s == 12345) r[0] += 1.f;           // keep the scalar chain alive
+    } else if constexpr (MODE == CMP_E64_CND) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool c = r[i] > r[(i + 1) & 15];     // both operands VGPRs -> SGPR-pair result
+        r[i] = c ? a : b;
       }
     } else if constexpr (MODE == PK_FMA || MODE == PK_CHAIN) {
 #pragma unroll
@@ -174,7 +221,7 @@ int run(int insts_per_iter) {
 int main(int argc, char **argv) {
   // VALU instructions per loop trip of every mode, counted from the ISA by
   // tools/ubench/run_valu_rate.sh (argv[1..N_MODES]); 0 skips a mode
-  int n[N_MODES] = {16, 16, 16, 48, 16, 8, 8, 0, 0};
+  int n[N_MODES] = {16, 16, 16, 48, 16, 8, 8, 0, 0, 16, 16, 16, 32, 16, 32, 32};
   for (int m = 0; m < N_MODES && m + 1 < argc; ++m) n[m] = atoi(argv[m + 1]);
   int rc = 0;
   rc |= run<INDEP_FMA>(n[INDEP_FMA]);
@@ -186,5 +233,12 @@ int main(int argc, char **argv) {
   rc |= run<PK_CHAIN>(n[PK_CHAIN]);
   rc |= run<COMPOSITE1>(n[COMPOSITE1]);
   rc |= run<COMPOSITE2>(n[COMPOSITE2]);
+  rc |= run<RCP_ALL>(n[RCP_ALL]);
+  rc |= run<PERMLANE32>(n[PERMLANE32]);
+  rc |= run<PERMLANE16>(n[PERMLANE16]);
+  rc |= run<DPP_ROW>(n[DPP_ROW]);
+  rc |= run<DPP_BCAST>(n[DPP_BCAST]);
+  rc |= run<READFIRST>(n[READFIRST]);
+  rc |= run<CMP_E64_CND>(n[CMP_E64_CND]);
   return rc;
 }
