@@ -222,8 +222,7 @@ def test_c5_window_vs_oracle():
     _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0, n_gauss=2_000_000)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("GSR_SLOW_TESTS") != "1",
-                    reason="full 1080p frame: the CPU oracle needs ~100 s (set GSR_SLOW_TESTS=1)")
 def test_c2_one_view_full_size_vs_oracle():
-    """The same at the real 1920x1080 (passes; kept out of the default run for its duration)."""
+    """The same at the real 1920x1080: one full c2 view against the CPU oracle (~1-2 min of oracle
+    time on the GPU box's 16 host threads)."""
     _c2_vs_oracle(W, H, 960.0, 540.0)
