@@ -325,23 +325,32 @@ attention_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, i
 #pragma unroll
     for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, st[r]);
     m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
-    const float m_new = fmaxf(m_run, m_loc);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    // Deferred maximum: the running reference m_run only moves when some query's tile maximum
+    // exceeds it by more than 2^8 in probability units -- until then the weights are taken
+    // relative to the stale reference (p <= 256, exact in the fp32 sums, 11-bit mantissa in the
+    // fp16 P operand either way) and the 32 accumulator registers are NOT rescaled. The final
+    // division by l_run cancels the reference, so the result is the same softmax.
+    if (__any((m_loc - m_run) * scale_log2e > 8.0f)) {
+      const float m_new = fmaxf(m_run, m_loc);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
+    const float mc = m_run * scale_log2e;
     float l_loc = 0.f;
     half8 pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f((st[r] - m_new) * scale_log2e);
+      const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], scale_log2e, -mc));
       l_loc += pv;
       pf[r >> 3][r & 7] = (h16)pv;
     }
     l_loc += __shfl_xor(l_loc, 32, 64);
-    l_run = l_run * alpha + l_loc;
-    m_run = m_new;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    l_run += l_loc;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
