@@ -30,6 +30,27 @@ __device__ __forceinline__ void coop_load_rows45(const float *__restrict__ shN, 
   }
 }
 
+// One degree band of the wave's 64 shN rows -- floats [O, O + WD) of each 45-float row -- into the
+// wave's LDS slab (row-major, WD floats per row: WD is odd, so lane l reading slab[l*WD + j] is
+// bank-conflict free). A wave-wide dword load covers 256 contiguous bytes of the band image, i.e.
+// 3-7 row segments, instead of one dword in each of 64 rows; the slab is 5.4 KB per wave at most
+// (the 11.5 KB of all 45 floats would cap the kernel at 3 waves/SIMD), and only the bands the
+// active degree uses are read. The slab is private to the wave: LDS operations of one wave
+// execute in order, so re-filling it for the next band needs no barrier.
+template <int O, int WD>
+__device__ __forceinline__ void coop_load_band(const float *__restrict__ shN, int64_t first_row,
+                                               float *__restrict__ slab, int lane) {
+  const float *src = shN + first_row * 45 + O;
+  __builtin_amdgcn_wave_barrier();   // (compiler ordering only: reads of the previous band stay above)
+#pragma unroll
+  for (int it = 0; it < WD; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / WD;
+    slab[idx] = src[row * 45 + (idx - row * WD)];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ opacities,
@@ -43,6 +64,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    float *__restrict__ colors_out, int color_stride, int depth_channel,
                    int activations, float *__restrict__ opacities_out, int tile_w, int tile_h,
                    int32_t *__restrict__ tile_counts, float *__restrict__ records) {
+  __shared__ float sBand[4 * 64 * 21];   // per-wave shN band slabs (coop_load_band)
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
   int c = (C == 1) ? 0 : (int)(g / N);   // (64-bit division only with several cameras)
@@ -86,14 +108,44 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   float *co = colors_out + g * color_stride;
   if (sh_degree >= 0) {
     float r = 0.f, gg = 0.f, b = 0.f;
-    if (p.rx > 0) {
+    const int lane = threadIdx.x & 63;
+    // every lane of the wave has a row of the same camera and the rows are the reference's 45 floats
+    const bool banded = sh_degree > 0 && shN_stride == 45 && (i - lane >= 0) && (i - lane + 63 < N);
+    if (banded) {
+      if (__any(p.rx > 0)) {
+        float *slab = &sBand[(threadIdx.x >> 6) * (64 * 21)];
+        const int64_t first = (int64_t)(i - lane);
+        float dx = mean[0] - campos[c * 3 + 0];
+        float dy = mean[1] - campos[c * 3 + 1];
+        float dz = mean[2] - campos[c * 3 + 2];
+        float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
+        const float *c0 = sh0 + (int64_t)i * sh0_stride;
+        const float *cn = slab;
+        gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
+                     [&](int k, float bk, float, float, float) {
+                       if (k == 1) {
+                         coop_load_band<0, 9>(shN, first, slab, lane);
+                         cn = slab + lane * 9 - 3;
+                       } else if (k == 4) {
+                         coop_load_band<9, 15>(shN, first, slab, lane);
+                         cn = slab + lane * 15 - 12;
+                       } else if (k == 9) {
+                         coop_load_band<24, 21>(shN, first, slab, lane);
+                         cn = slab + lane * 21 - 27;
+                       }
+                       const float *ck = (k == 0) ? c0 : cn + k * 3;
+                       r += bk * ck[0];
+                       gg += bk * ck[1];
+                       b += bk * ck[2];
+                     });
+        if (!(p.rx > 0)) r = gg = b = 0.f;
+      }
+    } else if (p.rx > 0) {
       float dx = mean[0] - campos[c * 3 + 0];
       float dy = mean[1] - campos[c * 3 + 1];
       float dz = mean[2] - campos[c * 3 + 2];
       float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
       const float *c0 = sh0 + (int64_t)i * sh0_stride;
-      // (a cooperative LDS read of the shN rows as in the backward was measured here and
-      // lost: 0.101 -> 0.112 ms, the 11.5 KB per wave caps this kernel at 3 waves/SIMD)
       const float *cn = shN + (int64_t)i * shN_stride;
       gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
                    [&](int k, float bk, float, float, float) {

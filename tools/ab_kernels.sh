@@ -1,0 +1,12 @@
+#!/bin/bash
+# Like ab_bench.sh, but prints every kernel's live time:  bash tools/ab_kernels.sh v0 v1 ...
+set -uo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+for NAME in "$@"; do
+  GSRAST_LIB="$ROOT/3dgs_monocular_depth_init_amd/lib/variants/libgsrast_$NAME.so" python3 "$ROOT/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > "$ROOT/gpurun_out/ab_$NAME.json" 2> "$ROOT/gpurun_out/ab_$NAME.err" || echo "$NAME failed"
+  python3 - "$ROOT/gpurun_out/ab_$NAME.json" "$NAME" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[2], "ms/step %.4f"%d["ms_per_step"], " ".join("%s=%.4f"%(k.replace("gsr_",""),v) for k,v in d["kernel_ms"].items()), flush=True)
+PY
+done
