@@ -260,17 +260,28 @@ transpose_v_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv,
 // (j&3); the V^T fragment (A operand) is read from LDS in that same key order.
 constexpr int KT = 32;        // keys per tile
 constexpr int LDK = 72;       // sK row stride (halves)
-constexpr int LDV = 40;       // sVt row stride (halves): 32 keys + 8 pad
+constexpr int LDV = 36;       // sVt row stride (halves): 32 keys + 4 pad = 18 dwords, so the 32 rows of a
+                              // half-wave's ds_read_b64 start in 32 distinct bank pairs (40 halves = 20
+                              // dwords put rows r and r + 16 on the same banks: SQ_LDS_BANK_CONFLICT 36 %)
 
-__global__ void __launch_bounds__(256)
+// SPLIT groups of 4 waves share a workgroup's 128 queries and take every SPLIT-th key tile each
+// (flash-decoding inside the workgroup): the sequence of this network is short -- 3349 tokens x
+// 16 heads are 1675 query waves for 1024 SIMDs, and a single wave per SIMD issues a VALU instruction
+// only every ~6 cycles (profiles/r02_valu_rate.jsonl), which is what bounds the softmax stream. The
+// groups' partial (O, m, l) are merged through LDS at the end.
+template <int SPLIT>
+__global__ void __launch_bounds__(256 * SPLIT)
 attention_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, int ld,
                  const h16 *__restrict__ vt, float scale_log2e, h16 *__restrict__ out, int ldo) {
-  __shared__ __attribute__((aligned(16))) h16 sK[2][KT * LDK];
-  __shared__ __attribute__((aligned(16))) h16 sV[2][64 * LDV];
+  constexpr int TILE_H = KT * LDK + 64 * LDV;                 // halves of one staged (K, Vt) tile pair
+  constexpr int STAGE_B = 2 * SPLIT * TILE_H * 2, MERGE_B = 4 * 34 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem_raw[STAGE_B > MERGE_B ? STAGE_B : MERGE_B];
+  h16 *smem = reinterpret_cast<h16 *>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, w4 = wave & 3, gt = tid & 255;
   const int lr = lane & 31, lh = lane >> 5;
   const int h = blockIdx.y, D = heads * 64;
-  const int q = blockIdx.x * 128 + wave * 32 + lr;
+  const int q = blockIdx.x * 128 + w4 * 32 + lr;
   const int qc = min(q, n_tok - 1);
 
   half8 qf[4];   // B operand of S^T: B[k = d][col = query]: lane (r, h) holds Q[q][16s + 8h + j]
@@ -278,19 +289,22 @@ attention_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, i
   for (int s = 0; s < 4; ++s)
     qf[s] = *reinterpret_cast<const half8 *>(qkv + (int64_t)qc * ld + h * 64 + s * 16 + lh * 8);
 
-  // staging: K tile = 32 keys x 64 d = 256 pieces of 16 B; Vt tile = 64 d x 32 keys = 256 pieces
-  const int k_row = tid >> 3, k_pc = (tid & 7) * 8;
-  const int v_row = tid >> 2, v_pc = (tid & 3) * 8;
+  // staging (per group): K tile = 32 keys x 64 d = 256 pieces of 16 B; Vt tile = 64 d x 32 keys
+  const int k_row = gt >> 3, k_pc = (gt & 7) * 8;
+  const int v_row = gt >> 2, v_pc = (gt & 3) * 8;
   const h16 *gk = qkv + D + h * 64 + k_pc;
   const h16 *gv = vt + ((int64_t)h * 64 + v_row) * n_pad + v_pc;
   uint4 rk, rv;
-  auto gload = [&](int key0) {
+  auto gload = [&](int key0) {   // (tiles past the sequence are clamped: read, never used)
     rk = *reinterpret_cast<const uint4 *>(gk + (int64_t)min(key0 + k_row, n_tok - 1) * ld);
-    rv = *reinterpret_cast<const uint4 *>(gv + key0);
+    rv = *reinterpret_cast<const uint4 *>(gv + min(key0, n_pad - KT));
   };
   auto sstore = [&](int buf) {
-    *reinterpret_cast<uint4 *>(&sK[buf][k_row * LDK + k_pc]) = rk;
-    *reinterpret_cast<uint4 *>(&sV[buf][v_row * LDV + v_pc]) = rv;
+    h16 *sK = smem + (buf * SPLIT + grp) * TILE_H, *sV = sK + KT * LDK;
+    *reinterpret_cast<uint4 *>(&sK[k_row * LDK + k_pc]) = rk;
+    // (Vt rows are 72 bytes apart: 8-byte aligned pieces)
+    *reinterpret_cast<uint2 *>(&sV[v_row * LDV + v_pc]) = make_uint2(rv.x, rv.y);
+    *reinterpret_cast<uint2 *>(&sV[v_row * LDV + v_pc + 4]) = make_uint2(rv.z, rv.w);
   };
 
   f32x16 o[2];
@@ -301,77 +315,111 @@ attention_kernel(int n_tok, int n_pad, int heads, const h16 *__restrict__ qkv, i
   float m_run = -1e30f, l_run = 0.f;
 
   const int n_tiles = (n_tok + KT - 1) / KT;
-  gload(0);
+  const int n_iter = (n_tiles + SPLIT - 1) / SPLIT;
+  gload(grp * KT);
   sstore(0);
   __syncthreads();
   int buf = 0;
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    if (kt + 1 < n_tiles) gload((kt + 1) * KT);
-    f32x16 st;
+  for (int it = 0; it < n_iter; ++it) {
+    const int key0 = (it * SPLIT + grp) * KT;
+    if (it + 1 < n_iter) gload(key0 + SPLIT * KT);
+    if (key0 < n_tok) {   // (wave-uniform; a group's surplus tile at the end is skipped)
+      const h16 *sK = smem + (buf * SPLIT + grp) * TILE_H, *sV = sK + KT * LDK;
+      f32x16 st;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const half8 kf = *reinterpret_cast<const half8 *>(&sK[buf][lr * LDK + s * 16 + lh * 8]);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
-    }
-    const int key0 = kt * KT;
-    if (key0 + KT > n_tok) {   // last tile: keys beyond the sequence take no weight
+      for (int s = 0; s < 4; ++s) {
+        const half8 kf = *reinterpret_cast<const half8 *>(&sK[lr * LDK + s * 16 + lh * 8]);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+      }
+      if (key0 + KT > n_tok) {   // last tile: keys beyond the sequence take no weight
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= n_tok) st[r] = -1e30f;
-    }
-    float m_loc = st[0];
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= n_tok) st[r] = -1e30f;
+      }
+      float m_loc = st[0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, st[r]);
-    m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
-    // Deferred maximum: the running reference m_run only moves when some query's tile maximum
-    // exceeds it by more than 2^8 in probability units -- until then the weights are taken
-    // relative to the stale reference (p <= 256, exact in the fp32 sums, 11-bit mantissa in the
-    // fp16 P operand either way) and the 32 accumulator registers are NOT rescaled. The final
-    // division by l_run cancels the reference, so the result is the same softmax.
-    if (__any((m_loc - m_run) * scale_log2e > 8.0f)) {
-      const float m_new = fmaxf(m_run, m_loc);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-      l_run *= alpha;
-      m_run = m_new;
+      for (int r = 1; r < 16; ++r) m_loc = fmaxf(m_loc, st[r]);
+      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+      // Deferred maximum: the running reference m_run only moves when some query's tile maximum
+      // exceeds it by more than 2^8 in probability units -- until then the weights are taken
+      // relative to the stale reference (p <= 256, exact in the fp32 sums, 11-bit mantissa in the
+      // fp16 P operand either way) and the 32 accumulator registers are NOT rescaled. The final
+      // division by l_run cancels the reference, so the result is the same softmax.
+      if (__any((m_loc - m_run) * scale_log2e > 8.0f)) {
+        const float m_new = fmaxf(m_run, m_loc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        l_run *= alpha;
+        m_run = m_new;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    }
-    const float mc = m_run * scale_log2e;
-    float l_loc = 0.f;
-    half8 pf[2];
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      }
+      const float mc = m_run * scale_log2e;
+      float l_loc = 0.f;
+      half8 pf[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], scale_log2e, -mc));
-      l_loc += pv;
-      pf[r >> 3][r & 7] = (h16)pv;
-    }
-    l_loc += __shfl_xor(l_loc, 32, 64);
-    l_run += l_loc;
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[r], scale_log2e, -mc));
+        l_loc += pv;
+        pf[r >> 3][r & 7] = (h16)pv;
+      }
+      l_loc += __shfl_xor(l_loc, 32, 64);
+      l_run += l_loc;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // A[row = d][k = 8h + j] = Vt[d][16s + 8(j>>2) + 4h + (j&3)]: two 8-byte reads
-        const h16 *vrow = &sV[buf][(t * 32 + lr) * LDV + s * 16 + lh * 4];
-        const half4 lo = *reinterpret_cast<const half4 *>(vrow);
-        const half4 hi = *reinterpret_cast<const half4 *>(vrow + 8);
-        half8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+          // A[row = d][k = 8h + j] = Vt[d][16s + 8(j>>2) + 4h + (j&3)]: two 8-byte reads
+          const h16 *vrow = &sV[(t * 32 + lr) * LDV + s * 16 + lh * 4];
+          const half4 lo = *reinterpret_cast<const half4 *>(vrow);
+          const half4 hi = *reinterpret_cast<const half4 *>(vrow + 8);
+          half8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o[t], 0, 0, 0);
+        }
       }
     }
-    if (kt + 1 < n_tiles) {
+    if (it + 1 < n_iter) {
       sstore(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
   }
-  if (q < n_tok) {
+  // merge the groups' partial results into group 0, one group at a time through LDS
+  // (float mb[4 waves][34][64 lanes]: 32 accumulators, m, l)
+  if (SPLIT > 1) {
+    float *mb = reinterpret_cast<float *>(smem_raw) + w4 * 34 * 64 + lane;
+#pragma unroll 1
+    for (int g = 1; g < SPLIT; ++g) {
+      __syncthreads();   // staging reads / the previous round's merge reads are done
+      if (grp == g) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mb[(t * 16 + r) * 64] = o[t][r];
+        mb[32 * 64] = m_run;
+        mb[33 * 64] = l_run;
+      }
+      __syncthreads();
+      if (grp == 0) {
+        const float m_o = mb[32 * 64], l_o = mb[33 * 64];
+        const float m_new = fmaxf(m_run, m_o);
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        const float a1 = __builtin_amdgcn_exp2f((m_o - m_new) * scale_log2e);
+        l_run = l_run * a0 + l_o * a1;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * a0 + mb[(t * 16 + r) * 64] * a1;
+      }
+    }
+  }
+  if (grp == 0 && q < n_tok) {
     const float inv = 1.0f / l_run;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -752,9 +800,19 @@ extern "C" int gsr_dn_attention(int n_tok, int n_pad, int heads, const void *qkv
   hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)gsr::ceil_div(n_pad, 64), (unsigned)heads),
                      dim3(256), 0, (hipStream_t)stream, n_tok, n_pad, heads, (const h16 *)qkv, ld,
                      (h16 *)vt_scratch);
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)gsr::ceil_div(n_tok, 128), (unsigned)heads),
-                     dim3(256), 0, (hipStream_t)stream, n_tok, n_pad, heads, (const h16 *)qkv, ld,
-                     (const h16 *)vt_scratch, scale * 1.4426950408889634f, (h16 *)out, ldo);
+  // key split: enough waves for ~3 per SIMD (1024 SIMDs), at most 4 groups per workgroup
+  const int q_waves = gsr::ceil_div(n_tok, 128) * 4 * heads;
+  // (measured at 3349 tokens: 16 heads 133 / 93 / 104 us with 1 / 2 / 4 groups, 6 heads 116 / 68 / 55)
+  const int split = (q_waves >= 3072 || n_tok <= 4 * 32) ? 1 : (q_waves >= 1536 ? 2 : 4);
+  const dim3 grid((unsigned)gsr::ceil_div(n_tok, 128), (unsigned)heads);
+#define GSR_ATT(S)                                                                                  \
+  hipLaunchKernelGGL(attention_kernel<S>, grid, dim3(256 * S), 0, (hipStream_t)stream, n_tok, n_pad, \
+                     heads, (const h16 *)qkv, ld, (const h16 *)vt_scratch,                           \
+                     scale * 1.4426950408889634f, (h16 *)out, ldo)
+  if (split == 1) GSR_ATT(1);
+  else if (split == 2) GSR_ATT(2);
+  else GSR_ATT(4);
+#undef GSR_ATT
   GSR_CHECK_LAUNCH("dn_attention");
   return GSR_OK;
 }

@@ -82,7 +82,9 @@ def test_gemm_epilogues_vs_torch(N):
     assert torch.allclose(r, res + gamma * z, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("n_tok,heads", [(101, 2), (3349, 6), (3349, 16)])
+# key split of the workgroup (gsr_dn_attention): (101, 2) and (1500, 64) run unsplit, (3349, 16) in two groups,
+# (3349, 6), (777, 3) and (150, 1) in four (25 and 5 key tiles: groups with a surplus tile at the end)
+@pytest.mark.parametrize("n_tok,heads", [(101, 2), (3349, 6), (3349, 16), (777, 3), (150, 1), (1500, 64)])
 def test_attention_vs_torch(N, n_tok, heads):
     lib = mod("_lib")
     D = heads * 64
