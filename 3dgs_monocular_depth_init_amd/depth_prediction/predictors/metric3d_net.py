@@ -68,10 +68,24 @@ class _Lin:
         self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
 
 
-def _conv_lin(w: torch.Tensor, b, device) -> _Lin:
-    """Conv2d weight [Cout, Cin, kh, kw] -> rows in im2col column order (ky*kw + kx)*Cin + c."""
-    co = w.shape[0]
-    return _Lin(w.permute(0, 2, 3, 1).reshape(co, -1), b, device)
+def _cpad(C: int) -> int:
+    """Channel count a map of C channels is STORED with: the next multiple of 64 from 32 channels on
+    (zero channels; a 3x3 convolution then reads its taps straight from the map, `gsr_dn_conv_gemm`,
+    at <= 1.5x the K of the im2col rows it replaces), the next multiple of 8 below that."""
+    return _ceil(C, 64) if C >= 32 else _ceil(C, 8)
+
+
+def _conv_lin(w: torch.Tensor, b, device, pad_cin: bool = True) -> _Lin:
+    """Conv2d weight [Cout, Cin, kh, kw] -> rows in im2col column order (ky*kw + kx)*Cin' + c, where
+    Cin' = _cpad(Cin) for a k x k kernel with k > 1 (zero weight planes for the map's zero channels)
+    and Cin for 1x1 kernels (a plain GEMM over the map's rows: the K padding of `_Lin` does it)."""
+    co, cin, kh, kw = w.shape
+    cin_p = _cpad(cin) if (pad_cin and kh * kw > 1 and cin >= 32) else cin
+    if cin_p != cin:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_p - cin))
+    lin = _Lin(w.permute(0, 2, 3, 1).reshape(co, -1), b, device)
+    lin.cin, lin.cin_p = cin, cin_p
+    return lin
 
 
 class Map:
@@ -79,8 +93,10 @@ class Map:
 
     def __init__(self, H, W, C, device, ld=None, t=None):
         self.H, self.W, self.C = H, W, C
-        self.ld = ld if ld is not None else _ceil(C, 8)
-        if t is None:    # padding channels must hold finite values (they meet zero weights in a GEMM)
+        self.ld = ld if ld is not None else _cpad(C)
+        # zpad: channels [C, ld) exist and hold zeros (allocated here; every kernel writes [0, C) only)
+        self.zpad = t is None
+        if t is None:
             alloc = torch.empty if self.ld == C else torch.zeros
             t = alloc(H * W, self.ld, dtype=torch.float16, device=device)
         self.t = t
@@ -192,22 +208,16 @@ class Metric3DNet:
         for g in ("gru08", "gru16", "gru32"):
             p = f"update_block.{g}."
             wz, wr, wq = sd[p + "convz.weight"], sd[p + "convr.weight"], sd[p + "convq.weight"]
-            cin = wz.shape[1]
-            # The concatenated GRU input [h | x...] is padded with zero channels (and the weights
-            # with zero input planes) up to a multiple of 64 when that costs < 25 % more K: the
-            # 3x3 convolutions then take the implicit-GEMM path instead of im2col rows (gru08's
-            # 6 flow channels make its 262 inputs the one odd size of the large model).
-            cin_pad = (cin + 63) // 64 * 64
-            if cin_pad > 1.25 * cin:
-                cin_pad = cin
-            padc = lambda w: torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - cin))
-            self.gru[g] = dict(
-                zr=_conv_lin(padc(torch.cat([wz, wr], 0)), torch.cat([sd[p + "convz.bias"], sd[p + "convr.bias"]]), dev),
-                q=_conv_lin(padc(wq), sd[p + "convq.bias"], dev), C=wz.shape[0], Cin=cin, Cin_pad=cin_pad)
+            # (the concatenated GRU input [h | x...] is one map of Cin channels, stored with _cpad(Cin):
+            # gru08's 262 = 256 + 6 flow channels of the large model become 320)
+            zr = _conv_lin(torch.cat([wz, wr], 0), torch.cat([sd[p + "convz.bias"], sd[p + "convr.bias"]]), dev)
+            self.gru[g] = dict(zr=zr, q=_conv_lin(wq, sd[p + "convq.bias"], dev), C=wz.shape[0], Cin=wz.shape[1])
         p = "update_block.flow_head."
         self.fh1 = _conv_lin(torch.cat([sd[p + "conv1d.weight"], sd[p + "conv1n.weight"]], 0),
                              torch.cat([sd[p + "conv1d.bias"], sd[p + "conv1n.bias"]]), dev)
-        self.fh2d, self.fh2n = conv(p + "conv2d"), conv(p + "conv2n")
+        # (their inputs are the two channel halves of fh1's output: views, read through im2col rows)
+        self.fh2d, self.fh2n = (_conv_lin(sd[p + k + ".weight"], sd.get(p + k + ".bias"), dev, pad_cin=False)
+                                for k in ("conv2d", "conv2n"))
         self.mask1, self.mask2 = conv("update_block.mask.0"), conv("update_block.mask.2")
 
     # ------------------------------------------------------------------ primitives
@@ -234,18 +244,23 @@ class Metric3DNet:
         otherwise im2col rows + `gsr_dn_gemm` (the 6-channel flow concatenations, small configs)."""
         pad = ks // 2
         Ho, Wo = (x.H + 2 * pad - ks) // stride + 1, (x.W + 2 * pad - ks) // stride + 1
-        assert (Ho, Wo) == (out.H, out.W) and lin.k == ks * ks * x.C, (lin.k, ks, x.C)
-        if x.C % 64 == 0 and stride == 1 and not relu_in and x.t.data_ptr() % 16 == 0:
+        assert (Ho, Wo) == (out.H, out.W), (Ho, Wo, out.H, out.W)
+        cin_p = getattr(lin, "cin_p", x.C)
+        # channels the taps are read with: the map's own when they are a multiple of 64, else the
+        # zero-padded count the weight was laid out for (the map must really hold those zeros)
+        cC = x.C if x.C % 64 == 0 else (cin_p if (x.zpad and x.ld >= cin_p and cin_p % 64 == 0) else 0)
+        if cC and lin.k == ks * ks * cC and stride == 1 and not relu_in and x.t.data_ptr() % 16 == 0:
             if getattr(self, "flop_count", None) is not None:
-                self.flop_count += 2.0 * Ho * Wo * lin.n * lin.k
+                self.flop_count += 2.0 * Ho * Wo * lin.n * ks * ks * x.C
             if getattr(self, "_zero_page", None) is None:
                 self._zero_page = torch.zeros(64, dtype=torch.float16, device=self.dev)
-            call("gsr_dn_conv_gemm", x.H, x.W, x.C, ptr(x.t), x.ld, ks, lin.n, lin.kp, ptr(lin.w), ptr(lin.b), act,
+            call("gsr_dn_conv_gemm", x.H, x.W, cC, ptr(x.t), x.ld, ks, lin.n, lin.kp, ptr(lin.w), ptr(lin.b), act,
                  None if residual is None else ptr(residual.t), 0 if residual is None else residual.ld,
                  ptr(out.t), out.ld, ptr(self._zero_page), _st())
             return out
-        if ks == 1 and not relu_in and x.ld >= lin.kp and x.C == lin.k and lin.kp == lin.k:
-            A, lda = x.t, x.ld
+        assert lin.k == ks * ks * x.C, ("weight laid out for padded channels, map not eligible", lin.k, ks, x.C, x.ld)
+        if ks == 1 and not relu_in and x.ld >= lin.kp and (lin.kp == lin.k or x.zpad):
+            A, lda = x.t, x.ld          # 1x1: the map's rows are the GEMM's rows (K padding = zero channels)
         else:
             rows = self._buf(f"im2col{Ho * Wo}x{lin.kp}", (Ho * Wo, lin.kp))
             call("gsr_dn_im2col", x.H, x.W, x.C, x.ld, ks, stride, pad, Ho, Wo, lin.kp, ptr(x.t), ptr(rows),
@@ -366,9 +381,7 @@ class Metric3DNet:
         G = self.gru[g]
         C = G["C"]
         Cin = G["Cin"]
-        hx = Map(h.H, h.W, G["Cin_pad"], self.dev)
-        if G["Cin_pad"] != Cin:
-            hx.t[:, Cin:].zero_()
+        hx = Map(h.H, h.W, Cin, self.dev)
         self.copy(h, hx.chan(0, C))
         c0 = C
         for x in xs:
@@ -419,6 +432,10 @@ class Metric3DNet:
         inter["ref_feat"] = ref_feat
         Cf = cfg["decoder_channels"][1]
         feat = ref_feat.chan(0, Cf)
+        if Cf % 64:           # a channel view has no zero channels behind it: give the two 3x3 heads a map of their own
+            own = Map(H4, W4, Cf, dev)
+            self.copy(feat, own)
+            feat = own
         P4 = H4 * W4
         # regress_depth (:806-838)
         t = self.conv(feat, self.dreg[0], 3, Map(H4, W4, N_BINS, dev), act=ACT_RELU)

@@ -115,9 +115,14 @@ def test_layernorm_conv_resize_pool_vs_torch(N):
     # 3x3 convolution through im2col + GEMM, stride 1 and C not a multiple of 8
     net = N.Metric3DNet.__new__(N.Metric3DNet)
     net.dev, net._scratch = torch.device("cuda"), {}
-    # (C % 64 == 0 without input ReLU takes the implicit-GEMM path, everything else im2col rows)
+    # (without input ReLU: C % 64 == 0 takes the implicit-GEMM path as is, 32 <= C with the map's zero
+    # channels up to the next multiple of 64 and zero weight planes for them -- 48, 96, 262 here;
+    # fewer than 32 channels, or an input ReLU, go through im2col rows; 1x1: the map's rows are the
+    # GEMM's rows, K padding = the zero channels)
     for C, Co, H, W, ks, relu_in in ((38, 16, 28, 42, 3, True), (64, 96, 44, 76, 3, True), (64, 96, 44, 76, 3, False),
-                                     (128, 258, 31, 45, 3, False), (192, 48, 17, 23, 1, False)):
+                                     (128, 258, 31, 45, 3, False), (192, 48, 17, 23, 1, False),
+                                     (48, 48, 44, 76, 3, False), (96, 32, 31, 45, 3, False), (262, 64, 23, 31, 3, False),
+                                     (6, 40, 28, 42, 3, False), (48, 96, 17, 23, 1, False), (102, 7, 17, 23, 1, False)):
         xin = torch.randn(1, C, H, W, generator=g)
         wt = torch.randn(Co, C, ks, ks, generator=g) / (ks * ks * C) ** 0.5
         bs = torch.randn(Co, generator=g)
@@ -127,8 +132,8 @@ def test_layernorm_conv_resize_pool_vs_torch(N):
         res.t.zero_()
         rin = torch.randn(H * W, Co, generator=g).half()
         res.t[:, :Co] = rin.cuda()
-        out = net.conv(m, N._conv_lin(wt, bs, "cuda"), ks, N.Map(H, W, Co, "cuda"), act=N.ACT_RELU, relu_in=relu_in,
-                       residual=res)
+        out = net.conv(m, N._conv_lin(wt, bs, "cuda", pad_cin=not relu_in), ks, N.Map(H, W, Co, "cuda"),
+                       act=N.ACT_RELU, relu_in=relu_in, residual=res)
         a = F.relu(xin.half().float()) if relu_in else xin.half().float()
         ref = F.relu(F.conv2d(a, wt.half().float(), bs, padding=ks // 2))[0].permute(1, 2, 0) + rin.float().view(H, W, Co)
         err = float((out.t[:, :Co].float().cpu().view(H, W, Co) - ref).abs().max())
