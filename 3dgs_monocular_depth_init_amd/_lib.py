@@ -66,6 +66,7 @@ SIGNATURES.update({
     "gsr_sfm_patch_mask": [_i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "gsr_depth_grad": [_i, _i, _p, _p, _p],
     "gsr_tri_interp": [_i, _i, _i, _p, _p, _p, _p, _p],
+    "gsr_region_margin_mask": [_i, _i, _i, _p, _p, _p, _p],
     "gsr_unproject_num_blocks": [_i, _i],
     "gsr_unproject_count": [_i, _i, _p, _p, _p, _p, _p, _p],
     "gsr_knn_cell_keys": [_i, _p, _p, _f, _p, _p],

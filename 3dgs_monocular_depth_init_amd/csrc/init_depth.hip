@@ -587,3 +587,52 @@ extern "C" int gsr_tri_interp(int H, int W, int n_tri, const double *xy, const i
   GSR_CHECK_LAUNCH("tri_interp");
   return GSR_OK;
 }
+
+// ---- F4 tail: region margin mask (depth_alignment/segmentation/region_margin.py:21-35) --------
+// The reference box-blurs the label map (replicate padding, k = 2m+1) in fp32, snaps values that
+// are `isclose` to an integer, and keeps the pixels whose blurred label equals their own: a pixel
+// is "interior" when its k x k window averages to its own label. Here the window SUM is exact
+// integer arithmetic (separable: row sums, then column sums, both with clamped coordinates =
+// replicate padding); the mean is the correctly rounded fp32 of S / k^2 and goes through the same
+// snap rule (|x - round(x)| <= 1e-8 + 1e-5 |round(x)|, torch.isclose's defaults), so that labels
+// large enough for the tolerance to exceed 1/k^2 behave as in the reference.
+namespace gsr {
+__global__ void __launch_bounds__(256)
+region_rowsum_kernel(int H, int W, int m, const int32_t *__restrict__ labels, int64_t *__restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+  const int32_t *row = labels + (int64_t)y * W;
+  int64_t s = 0;
+  for (int d = -m; d <= m; ++d) s += row[min(max(x + d, 0), W - 1)];
+  rows[i] = s;
+}
+
+__global__ void __launch_bounds__(256)
+region_margin_kernel(int H, int W, int m, const int32_t *__restrict__ labels,
+                     const int64_t *__restrict__ rows, uint8_t *__restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * W) return;
+  const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+  int64_t s = 0;
+  for (int d = -m; d <= m; ++d) s += rows[(int64_t)min(max(y + d, 0), H - 1) * W + x];
+  const int k = 2 * m + 1;
+  const float mean = (float)((double)s / (double)((int64_t)k * k));
+  const float nearest = rintf(mean);                                  // torch.round: half to even
+  const bool close = fabsf(mean - nearest) <= 1e-8f + 1e-5f * fabsf(nearest);
+  mask[i] = ((close ? nearest : mean) == (float)labels[i]) ? 1 : 0;
+}
+}  // namespace gsr
+
+extern "C" int gsr_region_margin_mask(int H, int W, int half_width, const int32_t *labels,
+                                      int64_t *row_sums, uint8_t *mask, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && half_width >= 0, "region_margin_mask: bad sizes");
+  GSR_REQUIRE(labels && row_sums && mask, "region_margin_mask: null pointer");
+  const unsigned nb = (unsigned)gsr::ceil_div64((int64_t)H * W, 256);
+  hipLaunchKernelGGL(gsr::region_rowsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, H, W, half_width,
+                     labels, row_sums);
+  hipLaunchKernelGGL(gsr::region_margin_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, H, W, half_width,
+                     labels, row_sums, mask);
+  GSR_CHECK_LAUNCH("region_margin_mask");
+  return GSR_OK;
+}

@@ -1,5 +1,6 @@
-"""depth_alignment/config.py:6-142 of the reference, restricted to the built strategies
-(segmentation-based alignment -- SLIC / SAM -- is out of scope)."""
+"""depth_alignment/config.py:6-142 of the reference. The two segmenters it names (SLIC: scikit-image,
+SAM: segment_anything + a ViT-H checkpoint) are third-party packages absent from this build;
+`DepthAlignmentPipeline` takes any callable with their signature instead."""
 from dataclasses import dataclass, field
 from enum import Enum
 from typing import Literal, Optional
@@ -19,6 +20,53 @@ class DepthAlignmentStrategyEnum(str, Enum):
             return DepthAlignmentInterpolate
         return {"lstsqrs": DepthAlignmentLstSqrs, "ransac": DepthAlignmentRansac,
                 "msac": DepthAlignmentMsac}[self.value]
+
+
+_SEGMENTERS = {}
+
+
+def register_segmenter(name: str, fn) -> None:
+    """Supply the implementation behind `segmenter="slic"` / `"sam"`: a callable
+    fn(predicted_depth, checkpoint_dir, segmentation_config) -> integer label map [H, W]
+    (the reference's DepthSegmentationFn, depth_alignment/interface.py:44-46)."""
+    _SEGMENTERS[DepthSegmentationStrategyEnum(name).value] = fn
+
+
+class DepthSegmentationStrategyEnum(str, Enum):      # config.py:36-51
+    slic = "slic"
+    sam = "sam"
+
+    def get_implementation(self):
+        if self.value in _SEGMENTERS:
+            return _SEGMENTERS[self.value]
+        raise NotImplementedError(
+            f"segmenter {self.value!r} is a third-party algorithm (scikit-image SLIC / segment_anything) that "
+            "this build does not contain: supply one with depth_alignment.config.register_segmenter(name, fn), "
+            "fn(predicted_depth, checkpoint_dir, segmentation_config) -> label map")
+
+
+@dataclass
+class SAMSegmentationconfig:        # config.py:54-75
+    use_normals: bool = True
+    degenerate_mask_thresh: float = 0.9
+    expansion_radius: int = 4
+    tiny_region_area_fraction: float = 1e-4
+
+
+@dataclass
+class SLICSegmentationConfig:       # config.py:78-81
+    compactness = 0.01
+    num_regions = 40
+
+
+@dataclass
+class DepthSegmentationConfig:      # config.py:84-101
+    region_margin: int = 10
+    propagate_mask: bool = False
+    min_border_grad_threshold: float = 0.0005
+    min_sfm_pts_in_region: int = 5
+    sam: SAMSegmentationconfig = field(default_factory=SAMSegmentationconfig)
+    slic: SLICSegmentationConfig = field(default_factory=SLICSegmentationConfig)
 
 
 @dataclass
@@ -42,7 +90,8 @@ class InterpConfig:                 # config.py:113-130
 
 @dataclass
 class DepthAlignmentConfig:         # config.py:133-142
-    segmenter: Optional[str] = None          # segmentation is out of scope: must stay None
+    segmenter: Optional[DepthSegmentationStrategyEnum] = None
     aligner: DepthAlignmentStrategyEnum = DepthAlignmentStrategyEnum.ransac
+    segmentation: DepthSegmentationConfig = field(default_factory=DepthSegmentationConfig)
     ransac: RansacConfig = field(default_factory=RansacConfig)
     interp: InterpConfig = field(default_factory=InterpConfig)

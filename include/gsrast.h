@@ -377,6 +377,12 @@ int gsr_sfm_patch_mask(int H, int W, int M, const int64_t *coords, int ph, int p
  * (`out` should be pre-filled with the fill value). */
 int gsr_tri_interp(int H, int W, int n_tri, const double *xy, const int32_t *tris, const double *values,
                    float *out, void *stream);
+/* F4 tail (depth_alignment/segmentation/region_margin.py:21-35, `calculate_region_margin_mask`):
+ * mask[i] = 1 where the (2*half_width+1)^2 box mean of the int32 label map (replicate padding),
+ * snapped to the nearest integer when torch.isclose to it, equals the pixel's own label -- the
+ * pixels farther than half_width from every region boundary. row_sums: int64 [H*W] scratch. */
+int gsr_region_margin_mask(int H, int W, int half_width, const int32_t *labels, int64_t *row_sums,
+                           uint8_t *mask, void *stream);
 /* B8 (points_from_depth.py:203-208): |dx| + |dy| backward differences. */
 int gsr_depth_grad(int H, int W, const float *depth, float *grad, void *stream);
 /* B9 (points_from_depth.py:270-312): fused mask -> ordered stream compaction ->

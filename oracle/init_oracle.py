@@ -130,6 +130,51 @@ def pipeline_align_noseg(aligned_depth: Tensor, predicted_mask: Tensor, aligner_
     return out_depth, (out_depth != INVALID_DEPTH_VAL) & predicted_mask
 
 
+# ---- F4 tail: segmentation/region_margin.py:6-35 + pipeline.py:193-288 --------
+def get_actual_margin_size(image_shape, region_margin) -> int:       # region_margin.py:16-18
+    return int(region_margin * max(image_shape) / 1297)
+
+
+def region_margin_mask(region_map: Tensor, region_margin: int) -> Tensor:
+    """calculate_region_margin_mask, region_margin.py:21-35: fp32 box blur of the label map
+    (utils/image_filtering.py:88-103: replicate padding, k x k kernel of 1/k^2), values
+    `isclose` to an integer snapped to it, compared with the labels."""
+    if region_margin == 0:
+        return torch.ones_like(region_map, dtype=torch.bool)
+    m = get_actual_margin_size(region_map.shape, region_margin)
+    k = 2 * m + 1
+    x = region_map[None, None].float()
+    padded = torch.nn.functional.pad(x, (m, m, m, m), mode="replicate")
+    blurred = torch.nn.functional.conv2d(padded, (torch.ones((k, k)) / (k * k))[None, None])[0, 0]
+    nearest = blurred.round()
+    blurred = torch.where(torch.isclose(blurred, nearest), nearest, blurred)
+    return blurred == region_map
+
+
+def pipeline_align_seg(depth_map: Tensor, mask: Tensor, coords: Tensor, gt: Tensor, segmentation: Tensor,
+                       region_margin: int, propagate_mask: bool, align_fn):
+    """The segmentation branch of DepthAlignmentPipeline.align (pipeline.py:193-288) after
+    region merging; align_fn(depth_map, coords, gt) -> aligned map (called region by region, in
+    ascending id order, so an RNG-consuming aligner draws as in the reference).
+    Returns (out_depth, out_mask, predicted mask after the optional propagation)."""
+    deadzone = region_margin_mask(segmentation, region_margin)
+    region_ids = torch.unique(segmentation[mask])
+    if propagate_mask:
+        mask = mask & deadzone
+    pts_regions = segmentation[coords[1], coords[0]]
+    pts_ok = deadzone[coords[1], coords[0]]
+    region_points = [torch.where((pts_regions == r) & pts_ok)[0] for r in region_ids]
+    out_depth = torch.full_like(depth_map, INVALID_DEPTH_VAL)
+    for region in region_ids:
+        idx = region_points[region.item()]            # indexed with the region ID, as the reference does
+        if idx.numel() == 0:
+            continue
+        aligned = align_fn(depth_map, coords[:, idx], gt[idx])
+        region_mask = segmentation == region
+        out_depth[region_mask] = aligned[region_mask]
+    return out_depth, (out_depth != INVALID_DEPTH_VAL) & mask, mask
+
+
 # ---- B5: depth_subsampling/static_subsampler.py:8-22 ------------------------
 def static_mask(depth_shape, k: int, mask: Tensor) -> Tensor:
     pixel_coords = torch.cartesian_prod(torch.arange(depth_shape[0]), torch.arange(depth_shape[1]))
