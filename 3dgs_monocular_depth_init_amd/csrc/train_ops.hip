@@ -190,6 +190,198 @@ strategy_accumulate_kernel(int C, int N, const float *__restrict__ grad, int gra
 
 }  // namespace gsr
 
+// ---------------------------------------------------------------------------------------------
+// F2: one-pass densification (DefaultStrategy refine step: duplicate -> split -> prune,
+// gsplat.strategy.ops as driven by gs_init_compare/runner.py:639-647). The three operations of a
+// refine step each rebuild all six parameter tensors and their twelve Adam moment tensors when
+// written as tensor ops; here the per-Gaussian decisions are one launch (refine_decide), their
+// output positions one scan, and every tensor is rebuilt by ONE multi-tensor gather launch.
+// Output order = what the three operations produce in sequence: surviving unsplit originals in
+// order, surviving duplicates in order, surviving split children (sample 0 block, sample 1 block).
+// flags rows (int32 [5,N]): original kept, duplicate kept, split children kept, is split (draws noise
+// whether or not its children survive), is duplicated (for the counts the strategy reports).
+namespace gsr {
+struct RefineParams {
+  float grow_grad2d, grow_scale3d, grow_scale2d /* < 0: off */, prune_opa, prune_scale3d /* < 0: off */,
+      prune_scale2d /* < 0: off */;
+  int revised_opacity;
+};
+
+__global__ void __launch_bounds__(256)
+refine_decide_kernel(int N, const float *__restrict__ log_scales, const float *__restrict__ logit_opac,
+                     const float *__restrict__ grad2d, const float *__restrict__ count,
+                     const float *__restrict__ radii_state, RefineParams rp, int32_t *__restrict__ flags4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float s0 = expf(log_scales[i * 3]), s1 = expf(log_scales[i * 3 + 1]), s2 = expf(log_scales[i * 3 + 2]);
+  const float smax = fmaxf(fmaxf(s0, s1), s2);
+  const float g = grad2d[i] / fmaxf(count[i], 1.0f);
+  const bool grad_high = g > rp.grow_grad2d;
+  const bool small = smax <= rp.grow_scale3d;
+  const float rad = radii_state ? radii_state[i] : 0.f;
+  const bool dup = grad_high && small;
+  bool split = grad_high && !small;
+  if (rp.grow_scale2d >= 0.f) split = split || (rad > rp.grow_scale2d);
+  // prune test on the values the surviving copy would carry
+  auto pruned = [&](float opac_logit, float scale_max) {
+    bool pr = (1.0f / (1.0f + expf(-opac_logit))) < rp.prune_opa;
+    if (rp.prune_scale3d >= 0.f) {
+      bool big = scale_max > rp.prune_scale3d;
+      if (rp.prune_scale2d >= 0.f) big = big || (rad > rp.prune_scale2d);
+      pr = pr || big;
+    }
+    return pr;
+  };
+  const float o = logit_opac[i];
+  const bool own_pruned = pruned(o, smax);
+  // children: scales log(exp(s) / 1.6) (re-exponentiated as the prune test reads them), opacity
+  // optionally 1 - sqrt(1 - sigmoid(o)) stored as a logit
+  const float c0 = expf(logf(s0 / 1.6f)), c1 = expf(logf(s1 / 1.6f)), c2 = expf(logf(s2 / 1.6f));
+  float oc = o;
+  if (rp.revised_opacity) {
+    const float no = 1.0f - sqrtf(1.0f - 1.0f / (1.0f + expf(-o)));
+    oc = logf(no / (1.0f - no));
+  }
+  const bool child_pruned = pruned(oc, fmaxf(fmaxf(c0, c1), c2));
+  flags4[i] = (!split && !own_pruned) ? 1 : 0;
+  flags4[N + i] = (dup && !own_pruned) ? 1 : 0;
+  flags4[2 * N + i] = (split && !child_pruned) ? 1 : 0;
+  flags4[3 * N + i] = split ? 1 : 0;
+  flags4[4 * N + i] = dup ? 1 : 0;
+}
+
+// incl4: inclusive scans of the four flag rows. src[r] = source row of output row r,
+// kind[r] = 0 original (keeps its Adam moments), 1 duplicate, 2 / 3 split child with sample 0 / 1.
+__global__ void __launch_bounds__(256)
+refine_plan_kernel(int N, const int32_t *__restrict__ flags4, const int32_t *__restrict__ incl4, int n0, int n1,
+                   int n2, int32_t *__restrict__ src, uint8_t *__restrict__ kind) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (flags4[i]) {
+    const int r = incl4[i] - 1;
+    src[r] = i;
+    kind[r] = 0;
+  }
+  if (flags4[N + i]) {
+    const int r = n0 + incl4[N + i] - 1;
+    src[r] = i;
+    kind[r] = 1;
+  }
+  if (flags4[2 * N + i]) {
+    const int e = incl4[2 * N + i] - 1;
+    src[n0 + n1 + e] = i;
+    kind[n0 + n1 + e] = 2;
+    src[n0 + n1 + n2 + e] = i;
+    kind[n0 + n1 + n2 + e] = 3;
+  }
+}
+
+constexpr int REFINE_MAX_TENSORS = 24;
+struct GatherArgs {
+  const float *src[REFINE_MAX_TENSORS];
+  float *dst[REFINE_MAX_TENSORS];
+  int row_len[REFINE_MAX_TENSORS];
+  int zero_new[REFINE_MAX_TENSORS];   // 1: rows of kind != 0 are zero (Adam moments of new Gaussians)
+};
+
+// blockIdx.y = tensor, blockIdx.x = a block of 256 output rows whose source rows and kinds are
+// staged in LDS once; the block then walks the 256 * L output elements of its rows linearly
+// (coalesced writes; reads are whole source rows). L is a compile-time constant for the row
+// lengths of the Gaussian parameters (1, 3, 4, 45) so that the element -> (row, column) split is a
+// multiply-shift, not a division.
+template <int LC>
+__device__ __forceinline__ void gather_rows(int rows, int L, const int32_t *sSrc, const uint8_t *sKind, bool zn,
+                                            const float *__restrict__ s, float *__restrict__ d) {
+  const int Lr = LC > 0 ? LC : L;
+  const int total = rows * Lr;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int r = e / Lr, c = e - r * Lr;
+    d[e] = (zn && sKind[r] != 0) ? 0.f : s[(int64_t)sSrc[r] * Lr + c];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+refine_gather_kernel(int M, const int32_t *__restrict__ src_row, const uint8_t *__restrict__ kind, GatherArgs a) {
+  __shared__ int32_t sSrc[256];
+  __shared__ uint8_t sKind[256];
+  const int t = blockIdx.y;
+  const int L = a.row_len[t];
+  const bool zn = a.zero_new[t] != 0;
+  const int r0 = blockIdx.x * 256;
+  const int rows = min(256, M - r0);
+  if (rows <= 0) return;
+  if ((int)threadIdx.x < rows) {
+    sSrc[threadIdx.x] = src_row[r0 + threadIdx.x];
+    sKind[threadIdx.x] = kind[r0 + threadIdx.x];
+  }
+  __syncthreads();
+  const float *s = a.src[t];
+  float *d = a.dst[t] + (int64_t)r0 * L;
+  switch (L) {
+    case 1: gather_rows<1>(rows, L, sSrc, sKind, zn, s, d); break;
+    case 3: gather_rows<3>(rows, L, sSrc, sKind, zn, s, d); break;
+    case 4: gather_rows<4>(rows, L, sSrc, sKind, zn, s, d); break;
+    case 45: gather_rows<45>(rows, L, sSrc, sKind, zn, s, d); break;
+    default: gather_rows<0>(rows, L, sSrc, sKind, zn, s, d); break;
+  }
+}
+}  // namespace gsr
+
+extern "C" int gsr_refine_decide(int N, const float *log_scales, const float *logit_opacities,
+                                 const float *grad2d, const float *count, const float *radii_state,
+                                 float grow_grad2d, float grow_scale3d, float grow_scale2d, float prune_opa,
+                                 float prune_scale3d, float prune_scale2d, int revised_opacity,
+                                 int32_t *flags4, void *stream) {
+  GSR_REQUIRE(N >= 0, "refine_decide: bad N");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(log_scales && logit_opacities && grad2d && count && flags4, "refine_decide: null pointer");
+  GSR_REQUIRE((grow_scale2d < 0.f && prune_scale2d < 0.f) || radii_state,
+              "refine_decide: screen-space thresholds need the radii statistic");
+  gsr::RefineParams rp{grow_grad2d, grow_scale3d, grow_scale2d, prune_opa, prune_scale3d, prune_scale2d,
+                       revised_opacity};
+  hipLaunchKernelGGL(gsr::refine_decide_kernel, dim3(gsr::ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                     log_scales, logit_opacities, grad2d, count, radii_state, rp, flags4);
+  GSR_CHECK_LAUNCH("refine_decide");
+  return GSR_OK;
+}
+
+extern "C" int gsr_refine_plan(int N, const int32_t *flags4, const int32_t *incl4, int n0, int n1, int n2,
+                               int32_t *src_row, uint8_t *kind, void *stream) {
+  GSR_REQUIRE(N >= 0 && n0 >= 0 && n1 >= 0 && n2 >= 0, "refine_plan: bad sizes");
+  if (N == 0) return GSR_OK;
+  GSR_REQUIRE(flags4 && incl4 && src_row && kind, "refine_plan: null pointer");
+  hipLaunchKernelGGL(gsr::refine_plan_kernel, dim3(gsr::ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                     flags4, incl4, n0, n1, n2, src_row, kind);
+  GSR_CHECK_LAUNCH("refine_plan");
+  return GSR_OK;
+}
+
+// src / dst: HOST arrays of n device pointers (fp32 tensors [*, row_len[i]] / [M, row_len[i]]);
+// row_len, zero_new: HOST arrays of n ints. n <= 24.
+extern "C" int gsr_refine_gather(int n, int M, const int32_t *src_row, const uint8_t *kind,
+                                 const void *const *src, void *const *dst, const int32_t *row_len,
+                                 const int32_t *zero_new, void *stream) {
+  GSR_REQUIRE(n >= 0 && n <= gsr::REFINE_MAX_TENSORS && M >= 0, "refine_gather: n=%d (max %d), M=%d", n,
+              gsr::REFINE_MAX_TENSORS, M);
+  if (n == 0 || M == 0) return GSR_OK;
+  GSR_REQUIRE(src_row && kind && src && dst && row_len && zero_new, "refine_gather: null array");
+  gsr::GatherArgs a;
+  int max_len = 1;
+  for (int i = 0; i < n; ++i) {
+    GSR_REQUIRE(src[i] && dst[i] && row_len[i] > 0, "refine_gather: tensor %d", i);
+    a.src[i] = (const float *)src[i];
+    a.dst[i] = (float *)dst[i];
+    a.row_len[i] = row_len[i];
+    a.zero_new[i] = zero_new[i];
+    max_len = row_len[i] > max_len ? row_len[i] : max_len;
+  }
+  (void)max_len;
+  hipLaunchKernelGGL(gsr::refine_gather_kernel, dim3((unsigned)gsr::ceil_div(M, 256), (unsigned)n), dim3(256), 0,
+                     (hipStream_t)stream, M, src_row, kind, a);
+  GSR_CHECK_LAUNCH("refine_gather");
+  return GSR_OK;
+}
+
 extern "C" int gsr_strategy_accumulate(int C, int N, const float *grad, int grad_stride,
                                        const int32_t *radii, float sx, float sy, float *grad2d,
                                        float *count, float *radii_state, float max_wh,

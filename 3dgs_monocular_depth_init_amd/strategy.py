@@ -146,6 +146,7 @@ class DefaultStrategy:
     verbose: bool = False
     key_for_gradient: str = "means2d"
     seed: int = 42                      # shared by all replicas (see module docstring)
+    one_pass: bool = True               # GPU: decide -> scan -> one multi-tensor gather (_refine_one_pass)
 
     def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
         return {"grad2d": None, "count": None, "scene_scale": scene_scale, "radii": None,
@@ -178,8 +179,11 @@ class DefaultStrategy:
         if (step > self.refine_start_iter and step % self.refine_every == 0
                 and step % self.reset_every >= self.pause_refine_after_reset):
             self._sync_state(state)
-            n_dupli, n_split = self._grow_gs(params, optimizers, state, step)
-            n_prune = self._prune_gs(params, optimizers, state, step)
+            if self.one_pass and params["means"].is_cuda:
+                n_dupli, n_split, n_prune = self._refine_one_pass(params, optimizers, state, step)
+            else:          # tensor-op formulation (CPU tensors: the unit tests of the bookkeeping)
+                n_dupli, n_split = self._grow_gs(params, optimizers, state, step)
+                n_prune = self._prune_gs(params, optimizers, state, step)
             if self.verbose:
                 print(f"Step {step}: {n_dupli} GSs duplicated, {n_split} GSs split, {n_prune} GSs "
                       f"pruned. Now having {len(params['means'])} GSs.")
@@ -251,6 +255,99 @@ class DefaultStrategy:
             g.manual_seed(self.seed)
             state["generator"] = g
         return state["generator"]
+
+    @torch.no_grad()
+    def _refine_one_pass(self, params, optimizers, state, step: int):
+        """duplicate -> split -> prune of a refine step as ONE rebuild of the tensors (csrc/train_ops.hip):
+        `gsr_refine_decide` takes every per-Gaussian decision (including the prune test on the
+        values a duplicate / a split child will carry), one scan gives the output positions, one host
+        read gives the new size, and `gsr_refine_gather` rebuilds all parameters and Adam moments
+        in a single launch -- instead of three passes of torch.cat / indexing over the 6 + 12
+        tensors with four host round trips. Same result as `_grow_gs` + `_prune_gs`, same row
+        order, same draws from the split generator (tests/test_gpu_train_ops.py)."""
+        from ._lib import ptr
+        call = _call()
+        dev = params["means"].device
+        st = torch.cuda.current_stream().cuda_stream
+        N = len(params["means"])
+        scene = state["scene_scale"]
+        use2d = step < self.refine_scale2d_stop_iter
+        scales, opac = params["scales"].detach(), params["opacities"].detach()
+        assert scales.is_contiguous() and opac.is_contiguous() and opac.numel() == N
+        flags = torch.empty(5, N, dtype=torch.int32, device=dev)
+        call("gsr_refine_decide", N, ptr(scales), ptr(opac), ptr(state["grad2d"]), ptr(state["count"]),
+             ptr(state["radii"]) if use2d else None, float(self.grow_grad2d), float(self.grow_scale3d * scene),
+             float(self.grow_scale2d) if use2d else -1.0, float(self.prune_opa),
+             float(self.prune_scale3d * scene) if step > self.reset_every else -1.0,
+             float(self.prune_scale2d) if use2d else -1.0, int(self.revised_opacity), ptr(flags), st)
+        incl = torch.empty_like(flags)
+        for r in range(5):          # (row by row: torch's scan of a few LONG rows in one call runs one workgroup per row, 3 ms at 1 M)
+            torch.cumsum(flags[r], 0, dtype=torch.int32, out=incl[r])
+        n0, n1, n2, ns, nd = (incl[:, -1].tolist() if N else (0, 0, 0, 0, 0))   # the one host round trip
+        M = n0 + n1 + 2 * n2
+        src = torch.empty(M, dtype=torch.int32, device=dev)
+        kind = torch.empty(M, dtype=torch.uint8, device=dev)
+        call("gsr_refine_plan", N, ptr(flags), ptr(incl), n0, n1, n2, ptr(src), ptr(kind), st)
+        # the split noise: drawn for EVERY split Gaussian, in index order, as split() draws it
+        samples = sel = None
+        if ns > 0:
+            sel = torch.nonzero_static(flags[3], size=ns).flatten()
+            sc_sel = torch.exp(scales[sel])
+            noise = torch.randn(2, ns, 3, device=dev, generator=self._generator(state, dev))
+            samples = torch.einsum("nij,nj,bnj->bni", _quat_to_rotmat(params["quats"].detach()[sel]), sc_sel, noise)
+        # every parameter and its two Adam moments through one gather launch
+        jobs, new_params, new_moments = [], {}, {}
+        for name, p in params.items():
+            old = p.detach()
+            if not (old.is_contiguous() and old.dtype == torch.float32):
+                raise ValueError(f"refine: parameter {name!r} must be contiguous fp32")
+            L = old[0].numel() if (old.dim() > 1 and N > 0) else max(1, int(old.numel() // max(N, 1)))
+            new_params[name] = torch.empty((M, *old.shape[1:]), dtype=torch.float32, device=dev)
+            jobs.append((old, new_params[name], L, 0))
+            stt = _opt_of(optimizers, name).state.get(p, {})
+            for k, v in stt.items():
+                if k != "step":
+                    nv = torch.empty((M, *v.shape[1:]), dtype=torch.float32, device=dev)
+                    new_moments[(name, k)] = nv
+                    jobs.append((v.contiguous(), nv, L, 1))
+        if M > 0 and N > 0:
+            import ctypes as C
+            for a in range(0, len(jobs), 24):
+                part = jobs[a:a + 24]
+                n = len(part)
+                PA = C.c_void_p * n
+                IA = C.c_int32 * n
+                call("gsr_refine_gather", n, M, ptr(src), ptr(kind), PA(*[ptr(j[0]) for j in part]),
+                     PA(*[ptr(j[1]) for j in part]), IA(*[j[2] for j in part]), IA(*[j[3] for j in part]), st)
+        if n2 > 0:          # what a split child differs in from its parent (rows [a, a + 2 n2): sample 0 block, sample 1 block)
+            a = n0 + n1
+            parent = src[a:a + n2].long()
+            rank = (incl[3] - 1)[parent].long()
+            new_params["means"][a:] += samples[:, rank].reshape(-1, 3)
+            new_params["scales"][a:] = torch.log(torch.exp(scales[parent]) / 1.6).repeat(2, 1)
+            if self.revised_opacity:
+                new_o = 1.0 - torch.sqrt(1.0 - torch.sigmoid(opac[parent]))
+                new_params["opacities"][a:] = torch.logit(new_o).repeat(2)
+        # hand the rebuilt tensors to the parameter dict and the optimizers (as _update_param_with_optimizer)
+        for name in list(params.keys()):
+            old = params[name]
+            new = torch.nn.Parameter(new_params[name], requires_grad=old.requires_grad)
+            opt = _opt_of(optimizers, name)
+            for g in opt.param_groups:
+                for i, p in enumerate(g["params"]):
+                    if p is old:
+                        stt = opt.state.pop(p, {})
+                        for k in list(stt.keys()):
+                            if k != "step":
+                                stt[k] = new_moments[(name, k)]
+                        g["params"][i] = new
+                        if stt:
+                            opt.state[new] = stt
+            params[name] = new
+        for k, v in list(state.items()):
+            if isinstance(v, Tensor) and v.dim() > 0:
+                state[k] = torch.zeros(M, dtype=v.dtype, device=dev)      # (the caller zeroes them anyway)
+        return nd, ns, N + nd + ns - M          # duplicated, split, pruned (as _grow_gs / _prune_gs count them)
 
     def _grow_gs(self, params, optimizers, state, step: int):
         count = state["count"]

@@ -250,6 +250,30 @@ int gsr_adam_step(int n, void *const *params, const void *const *grads, void *co
                   const float *bc2_sqrt, double beta1, double beta2, double eps, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * F2: DefaultStrategy refine step in one pass (duplicate -> split -> prune of
+ * gsplat.strategy.ops, driven by gs_init_compare/runner.py:639-647; thresholds
+ * gs_init_compare/config.py:204-221).
+ * gsr_refine_decide: flags4 int32 [5,N] = {original kept, duplicate kept, split children kept,
+ *   is split, is duplicated} from the strategy's statistics and the raw (log / logit) parameters. Thresholds are
+ *   absolute (already multiplied by scene_scale); grow_scale2d / prune_scale2d < 0 switch the
+ *   screen-space tests off (step >= refine_scale2d_stop_iter), prune_scale3d < 0 the size prune
+ *   (step <= reset_every).
+ * gsr_refine_plan: from the inclusive scans incl4 (rows 0..2 are read) of flags4 and the totals n0, n1, n2 of
+ *   rows 0..2: src_row / kind for the M = n0 + n1 + 2*n2 output rows (kind 0 original,
+ *   1 duplicate, 2 / 3 split child with noise sample 0 / 1).
+ * gsr_refine_gather: dst[t][r] = src[t][src_row[r]] for n tensors in one launch; tensors with
+ *   zero_new[t] (Adam moments) get zeros in rows of kind != 0. HOST pointer arrays, n <= 24.
+ * --------------------------------------------------------------------------*/
+int gsr_refine_decide(int N, const float *log_scales, const float *logit_opacities, const float *grad2d,
+                      const float *count, const float *radii_state /* or NULL */, float grow_grad2d,
+                      float grow_scale3d, float grow_scale2d, float prune_opa, float prune_scale3d,
+                      float prune_scale2d, int revised_opacity, int32_t *flags4, void *stream);
+int gsr_refine_plan(int N, const int32_t *flags4, const int32_t *incl4, int n0, int n1, int n2,
+                    int32_t *src_row, uint8_t *kind, void *stream);
+int gsr_refine_gather(int n, int M, const int32_t *src_row, const uint8_t *kind, const void *const *src,
+                      void *const *dst, const int32_t *row_len, const int32_t *zero_new, void *stream);
+
+/* ---------------------------------------------------------------------------
  * F1: fused L1 + SSIM loss (gs_init_compare/runner.py:506-510; replaces the
  * third-party `fused_ssim`, setup.py:14). Images are logical [N,CH,H,W] fp32
  * addressed by ELEMENT strides (HOST int64[4]), so NHWC renders are used in

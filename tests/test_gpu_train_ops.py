@@ -406,3 +406,55 @@ def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
         assert float(fused["means"].state[splats["means"]]["step"]) == 2.0
     finally:
         R.set_backward_optimizer(None)
+
+
+@pytest.mark.parametrize("step,scale2d_stop,revised", [(700, 0, False), (3500, 0, True), (3500, 5000, False),
+                                                       (600, 5000, True)])
+def test_one_pass_refine_equals_duplicate_split_prune(step, scale2d_stop, revised):
+    """DefaultStrategy._refine_one_pass (gsr_refine_decide / _plan / _gather) against the sequence of
+    tensor operations it replaces (duplicate -> split -> remove, `_grow_gs` + `_prune_gs`) on the
+    same parameters, Adam moments, statistics and generator seed: identical sizes, identical row
+    order, bit-identical tensors. Cases: before / after the first opacity reset (the size prune is
+    off until then), with and without the screen-space tests, with and without revised opacities."""
+    S = importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+    g = torch.Generator().manual_seed(step + scale2d_stop)
+    N = 20000
+    base = {"means": torch.randn(N, 3, generator=g), "scales": torch.randn(N, 3, generator=g) * 0.8 - 4.0,
+            "quats": torch.randn(N, 4, generator=g), "opacities": torch.randn(N, generator=g) * 3.0,
+            "sh0": torch.randn(N, 1, 3, generator=g), "shN": torch.randn(N, 15, 3, generator=g)}
+    moments = {k: (torch.randn(v.shape, generator=g), torch.rand(v.shape, generator=g)) for k, v in base.items()}
+    grad2d = torch.rand(N, generator=g) * 8e-4
+    count = torch.randint(0, 4, (N,), generator=g).float()
+    radii = torch.rand(N, generator=g) * 0.2
+
+    def run(one_pass):
+        strat = S.DefaultStrategy(refine_scale2d_stop_iter=scale2d_stop, revised_opacity=revised, one_pass=one_pass,
+                                  grow_scale3d=0.02, prune_scale3d=0.06)
+        params = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().cuda()) for k, v in base.items()})
+        opts = {k: torch.optim.Adam([{"params": params[k], "lr": 1e-3, "name": k}]) for k in params}
+        for k in params:
+            opts[k].state[params[k]] = {"step": torch.tensor(7.0), "exp_avg": moments[k][0].clone().cuda(),
+                                        "exp_avg_sq": moments[k][1].clone().cuda()}
+        state = strat.initialize_state(scene_scale=1.3)
+        state["grad2d"], state["count"] = grad2d.clone().cuda(), count.clone().cuda()
+        if scale2d_stop > 0:
+            state["radii"] = radii.clone().cuda()
+        if one_pass:
+            counts = strat._refine_one_pass(params, opts, state, step)
+        else:
+            nd, ns = strat._grow_gs(params, opts, state, step)
+            counts = (nd, ns, strat._prune_gs(params, opts, state, step))
+        out = {k: params[k].detach().cpu() for k in params}
+        for k in params:
+            st = opts[k].state[params[k]]
+            assert float(st["step"]) == 7.0 and opts[k].param_groups[0]["params"][0] is params[k]
+            out[k + ".m"], out[k + ".v"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+        assert all(state[k].shape[0] == len(params["means"]) for k in ("grad2d", "count"))
+        return counts, out
+
+    c_ref, ref = run(False)
+    c_got, got = run(True)
+    assert c_got == c_ref and min(c_ref) > 100, (c_got, c_ref)       # every operation takes part
+    for k in ref:
+        assert got[k].shape == ref[k].shape, k
+        assert torch.equal(got[k], ref[k]), k
