@@ -73,6 +73,8 @@ SIGNATURES.update({
     "gsr_unproject_num_blocks": [_i, _i],
     "gsr_unproject_count": [_i, _i, _p, _p, _p, _p, _p, _p],
     "gsr_knn_cell_keys": [_i, _p, _p, _f, _p, _p],
+    "gsr_knn_grid_idx": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _i, _p, _p, _p, _p],
+    "gsr_lof": [_i, _i, _p, _p, C.c_double, _p, _p, _p, _p],
     "gsr_knn_grid": [_i, _i, _p, _p, _p, _p, _p, _i, _p, _f, _i, _p, _p, _p],
     "gsr_knn_brute": [_i, _i, _i, _p, _p, _p, _p],
     "gsr_m3d_preprocess": [_i, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],

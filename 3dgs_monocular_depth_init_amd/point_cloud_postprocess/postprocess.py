@@ -6,8 +6,10 @@ Mirror of /root/reference/gs_init_compare/point_cloud_postprocess/postprocess.py
 camera_2_world_matrices, image_sizes, params)`
 (native_modules/subsampling/src/pointcloud_subsampling.cpp:22-67, C++/Eigen there;
 csrc/pointcloud.hip here). Both switches are off by default in the reference
-(point_cloud_postprocess/config.py:15-17). LOF outlier removal (scikit-learn on the CPU) is
-not built.
+(point_cloud_postprocess/config.py:15-17). LOF outlier removal (postprocess.py:16-22: scikit-learn's
+LocalOutlierFactor on the CPU, all cores) is `knn.local_outlier_factor` on the GPU: exact 40 nearest
+neighbours by a cell-grid ring search, then the two LOF passes; pinned by the output of
+scikit-learn itself (tests/golden/make_lof_golden.py).
 """
 from __future__ import annotations
 
@@ -67,11 +69,24 @@ def subsample_pointcloud(points, rgbs, intrinsic_matrices, camera_2_world_matric
     return p.cpu().numpy(), c.cpu().numpy(), e.cpu().numpy(), empty, empty.copy()
 
 
+def lof_outlier_removal(pts: torch.Tensor, config: PointCloudPostprocessConfig) -> torch.Tensor:
+    """postprocess.py:16-22: True where LocalOutlierFactor(n_neighbors=config.lof_num_neighbors) predicts -1."""
+    from ..knn import local_outlier_factor
+    return local_outlier_factor(pts, config.lof_num_neighbors)[0]
+
+
+def get_outlier_removal_func(method: OutlierRemovalMethod):          # postprocess.py:25-29
+    if method == OutlierRemovalMethod.lof:
+        return lof_outlier_removal
+    raise ValueError(f"Unknown outlier removal method: {method}")
+
+
 def postprocess_point_cloud(pts: torch.Tensor, rgbs: torch.Tensor, intrinsic_matrices, proj_matrices, image_sizes,
                             config: PointCloudPostprocessConfig, device):
     """postprocess.py:25-77 (PLY debug exports not produced)."""
     if config.outlier_removal != OutlierRemovalMethod.off:
-        raise NotImplementedError("LOF outlier removal (scikit-learn, CPU) is out of scope of this build")
+        outliers = get_outlier_removal_func(config.outlier_removal)(pts.to(device), config)
+        pts, rgbs = pts.to(device)[~outliers], rgbs.to(device)[~outliers]     # (postprocess.py:41-58, no PLY exports)
     if config.subsample:
         Ks = torch.as_tensor(np.stack([np.asarray(k) for k in intrinsic_matrices]), dtype=torch.float32)
         Ps = torch.as_tensor(np.stack([np.asarray(m) for m in proj_matrices]), dtype=torch.float32)

@@ -443,6 +443,20 @@ int gsr_knn_grid(int N, int K, const float *queries /* [N,3] */, const float *so
                  int max_ring, float *out, uint8_t *unresolved, void *stream);
 int gsr_knn_brute(int Q, int N, int K, const float *queries, const float *pts, float *out,
                   void *stream);
+/* F4 tail (point_cloud_postprocess/postprocess.py:16-22: sklearn LocalOutlierFactor on the CPU).
+ * gsr_knn_grid_idx: like gsr_knn_grid with K <= 64 and the neighbours' indices: out_dist fp64
+ *   [*,K] ascending (sqrt of fp64 squared distances), out_idx int32 [*,K] = sorted_ids of the
+ *   neighbours; self_pos[i] (or NULL) = position in sorted_pts of query i itself, skipped;
+ *   qorder[i] (or NULL: i) = output row of query i; unresolved as in gsr_knn_grid.
+ * gsr_lof: local reachability density and negative outlier factor (sklearn/neighbors/_lof.py
+ *   `_local_reachability_density`, `fit`): lrd[N] scratch/out, negative_outlier_factor[N] or NULL,
+ *   outlier[i] = negative_outlier_factor < offset (-1.5 for contamination="auto"). */
+int gsr_knn_grid_idx(int Q, int K, const float *queries, const int64_t *self_pos, const float *sorted_pts,
+                     const int64_t *sorted_ids, const int64_t *qorder, const int64_t *ukeys,
+                     const int64_t *ustart, int U, const float *origin, float h, int max_ring,
+                     double *out_dist, int32_t *out_idx, uint8_t *unresolved, void *stream);
+int gsr_lof(int N, int K, const double *dist, const int32_t *idx, double offset, double *lrd,
+            double *negative_outlier_factor, uint8_t *outlier, void *stream);
 
 /* B10: Metric3D pre/post-processing (depth_prediction/predictors/metric3d.py:42-83,
  * 96-131) around the depth network. preprocess: float RGB [H,W,3] in [0,1] ->
