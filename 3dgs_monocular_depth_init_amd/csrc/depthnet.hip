@@ -86,10 +86,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // one tap, so every lane's chunk is one 16-byte piece of a neighbouring pixel -- fetched straight from
 // the map (out-of-image taps and the K padding come from a zero page): no im2col buffer is written
 // or re-read.
-template <int ACT, bool CONV>
+// BNT = 128: the 128x128 tile, 2x2 MFMA tiles per wave. BNT = 64: a 128x64 tile (each wave 64x32,
+// 48 KB of LDS) for the launches whose 128x128 grid would leave the chip underfilled -- M = 3349
+// tokens are 27 row tiles, so N = 1024 gives 216 workgroups for 256 CUs with nothing to overlap
+// with; twice as many half-size workgroups, three resident per CU, finish sooner.
+template <int ACT, bool CONV, int BNT>
 __global__ void __launch_bounds__(256, 2)
 gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) h16 smem[2][2][BM * BK];   // [buffer][A|B][row][k]
+  constexpr int NBS = BNT / 32;     // B staging instructions per wave
+  constexpr int NJ = BNT / 64;      // 32-column MFMA tiles per wave
+  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM + BNT) * BK];   // [buffer][A rows | B rows][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs; remap so that
@@ -100,12 +106,13 @@ gemm_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
     wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
   }
-  const int m0 = (wg / nbx) * BM, n0 = (wg % nbx) * BN;
+  const int m0 = (wg / nbx) * BM, n0 = (wg % nbx) * BNT;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // staging: wave w, instruction i moves rows (4w + i)*8 .. +7; lane -> (row, physical chunk)
+  // staging: wave w, instruction i moves rows (4w + i)*8 .. +7 of A (NBS*w + i for B);
+  // lane -> (row, physical chunk)
   const int srow = lane >> 3, pch = lane & 7;
-  const h16 *ga[4], *gb[4];
+  const h16 *ga[4], *gb[NBS];
   int pix_y[4], pix_x[4], lch[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -119,7 +126,11 @@ gemm_kernel(GemmArgs p) {
     } else {
       ga[i] = p.A + (int64_t)m * p.lda + lch[i];
     }
-    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NBS; ++i) {
+    const int r = (wave * NBS + i) * 8 + srow;
+    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + (pch ^ ((r >> 1) & 7)) * 8;
   }
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -143,19 +154,26 @@ gemm_kernel(GemmArgs p) {
       } else {
         src = ga[i] + k0;
       }
-      h16 *dA = &smem[buf][0][(wave * 4 + i) * 8 * BK];
-      h16 *dB = &smem[buf][1][(wave * 4 + i) * 8 * BK];
+      h16 *dA = &smem[buf][(wave * 4 + i) * 8 * BK];
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dA, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NBS; ++i) {
+      h16 *dB = &smem[buf][BM * BK + (wave * NBS + i) * 8 * BK];
       __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + k0), (lds_void *)dB, 16, 0, 0);
     }
   };
 
-  f32x16 acc00, acc01, acc10, acc11;
+  f32x16 acc[2][NJ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc00[r] = acc01[r] = acc10[r] = acc11[r] = 0.f;
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment rows of this lane and their swizzle terms
-  const int ra0 = wm * 64 + lr, ra1 = ra0 + 32, rb0 = wn * 64 + lr, rb1 = rb0 + 32;
+  const int ra0 = wm * 64 + lr, ra1 = ra0 + 32, rb0 = wn * (BNT / 2) + lr, rb1 = rb0 + 32;
   const int xa0 = (ra0 >> 1) & 7, xa1 = (ra1 >> 1) & 7, xb0 = (rb0 >> 1) & 7, xb1 = (rb1 >> 1) & 7;
 
   const int nk = p.K / BK;
@@ -164,26 +182,28 @@ gemm_kernel(GemmArgs p) {
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
-    const h16 *sA = smem[buf][0], *sB = smem[buf][1];
+    const h16 *sA = smem[buf], *sB = smem[buf] + BM * BK;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int cl = 2 * s + lh;
       const half8 af0 = *reinterpret_cast<const half8 *>(sA + ra0 * BK + ((cl ^ xa0) << 3));
       const half8 af1 = *reinterpret_cast<const half8 *>(sA + ra1 * BK + ((cl ^ xa1) << 3));
       const half8 bf0 = *reinterpret_cast<const half8 *>(sB + rb0 * BK + ((cl ^ xb0) << 3));
-      const half8 bf1 = *reinterpret_cast<const half8 *>(sB + rb1 * BK + ((cl ^ xb1) << 3));
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc11, 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf0, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc[1][0], 0, 0, 0);
+      if constexpr (NJ == 2) {
+        const half8 bf1 = *reinterpret_cast<const half8 *>(sB + rb1 * BK + ((cl ^ xb1) << 3));
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc[1][1], 0, 0, 0);
+      }
     }
     __syncthreads();          // tile kt+1 has landed, and every wave is done reading tile kt
     buf ^= 1;
   }
 
   // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
-  auto emit = [&](const f32x16 &acc, int i, int j) {
-    const int n = n0 + wn * 64 + j * 32 + lr;
+  auto emit = [&](const f32x16 &a, int i, int j) {
+    const int n = n0 + wn * (BNT / 2) + j * 32 + lr;
     if (n >= p.N) return;
     const float b = p.bias ? p.bias[n] : 0.f;
     const float g = p.gamma ? p.gamma[n] : 1.f;
@@ -192,17 +212,17 @@ gemm_kernel(GemmArgs p) {
     for (int r = 0; r < 16; ++r) {
       const int m = mb + (r & 3) + 8 * (r >> 2);
       if (m >= p.M) continue;
-      float v = act_fn<ACT>(acc[r] + b) * g;
+      float v = act_fn<ACT>(a[r] + b) * g;
       if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
       if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
       if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
       if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
     }
   };
-  emit(acc00, 0, 0);
-  emit(acc01, 0, 1);
-  emit(acc10, 1, 0);
-  emit(acc11, 1, 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) emit(acc[i][j], i, j);
 }
 
 // ---- LayerNorm over the last dimension: one wave per row, fp32 statistics -------------------
@@ -719,15 +739,35 @@ using namespace gsr::dn;
 
 template <bool CONV>
 static int launch_gemm(const GemmArgs &p, void *stream) {
-  dim3 grid((unsigned)gsr::ceil_div(p.N, gsr::dn::BN), (unsigned)gsr::ceil_div(p.M, gsr::dn::BM));
   hipStream_t st = (hipStream_t)stream;
-  switch (p.act) {
-    case ACT_GELU: hipLaunchKernelGGL((gemm_kernel<ACT_GELU, CONV>), grid, dim3(256), 0, st, p); break;
-    case ACT_RELU: hipLaunchKernelGGL((gemm_kernel<ACT_RELU, CONV>), grid, dim3(256), 0, st, p); break;
-    case ACT_SIGMOID: hipLaunchKernelGGL((gemm_kernel<ACT_SIGMOID, CONV>), grid, dim3(256), 0, st, p); break;
-    case ACT_TANH: hipLaunchKernelGGL((gemm_kernel<ACT_TANH, CONV>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_kernel<ACT_NONE, CONV>), grid, dim3(256), 0, st, p); break;
+  const int rows = gsr::ceil_div(p.M, gsr::dn::BM);
+  // Tile width by a wave-quantisation model of the 256 CUs: 2 resident 128x128 workgroups per CU
+  // (64 KB of LDS each) or 3 of 128x64 (48 KB), a 128x64 workgroup taking ~0.7 of the time of a
+  // 128x128 one; the launch runs ceil(workgroups / resident slots) rounds. Measured at 3349 tokens:
+  // N = 1024 (216 -> 432 workgroups) 26.6 -> 18.5 us at K = 1024 and 59 -> 48 us at K = 4096,
+  // N = 3072 (648 = 2 rounds -> 1296) 53 -> 45 us; the 1/7-resolution convolution (420 workgroups, one
+  // round) stays wide: 86 us against 116 us narrow.
+  const int b128 = rows * gsr::ceil_div(p.N, 128), b64 = rows * gsr::ceil_div(p.N, 64);
+  // (only where the rounding matters, up to two rounds: 8192^3 is 1390 us wide, 1560 us narrow)
+  const bool narrow = p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512);
+#define GSR_GEMM(A, BNT_)                                                                             \
+  hipLaunchKernelGGL((gemm_kernel<A, CONV, BNT_>), dim3((unsigned)gsr::ceil_div(p.N, BNT_), (unsigned)rows), \
+                     dim3(256), 0, st, p)
+#define GSR_GEMM_ACT(BNT_)                         \
+  switch (p.act) {                                 \
+    case ACT_GELU: GSR_GEMM(ACT_GELU, BNT_); break;       \
+    case ACT_RELU: GSR_GEMM(ACT_RELU, BNT_); break;       \
+    case ACT_SIGMOID: GSR_GEMM(ACT_SIGMOID, BNT_); break; \
+    case ACT_TANH: GSR_GEMM(ACT_TANH, BNT_); break;       \
+    default: GSR_GEMM(ACT_NONE, BNT_); break;             \
   }
+  if (narrow) {
+    GSR_GEMM_ACT(64)
+  } else {
+    GSR_GEMM_ACT(128)
+  }
+#undef GSR_GEMM_ACT
+#undef GSR_GEMM
   GSR_CHECK_LAUNCH("dn_gemm");
   return GSR_OK;
 }
