@@ -31,7 +31,7 @@ SIGNATURES = {
     "gsr_isect_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _p],
     "gsr_tile_sort": [_i, _p, _p, _p, _p, _p, _p],
     "gsr_bucket_layout": [_i, _i, _i, _p, _p],
-    "gsr_isect_scan_clear": [_i, _p, _p, _p, _p],
+    "gsr_isect_scan_clear": [_i, _p, _p, _p, _p, _p],
     "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _i, _p],
     "gsr_bucket_emit": [_i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i64, _i, _p],
     "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _i64, _p, _p],

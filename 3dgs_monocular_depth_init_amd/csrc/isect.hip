@@ -66,7 +66,7 @@ __device__ __forceinline__ int order_bucket(int len) {
 template <bool CLEAR>
 __global__ void __launch_bounds__(1024)
 scan_kernel(int n, int32_t *__restrict__ in, int32_t *__restrict__ out,
-            int32_t *__restrict__ tile_order) {
+            int32_t *__restrict__ tile_order, int32_t *__restrict__ total_host = nullptr) {
   __shared__ int32_t wave_tot[16];
   __shared__ int32_t carry_s;
   __shared__ int32_t hist[ORDER_BUCKETS];
@@ -104,7 +104,13 @@ scan_kernel(int n, int32_t *__restrict__ in, int32_t *__restrict__ out,
     if (tid == 1023) carry_s = carry + wave_prefix + incl;
     __syncthreads();
   }
-  if (tid == 0) out[n] = carry_s;
+  if (tid == 0) {
+    out[n] = carry_s;
+    // the host's copy of the total, stored straight into pinned host memory (no copy launch
+    // between this kernel and the emit kernel); visible once an event recorded after this
+    // kernel has completed
+    if (total_host) __hip_atomic_store(total_host, carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (!tile_order) {
     if (CLEAR) {
       __syncthreads();
@@ -266,10 +272,10 @@ extern "C" int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *
 }
 
 extern "C" int gsr_isect_scan_clear(int n, int32_t *counts, int32_t *offsets, int32_t *order,
-                                    void *stream) {
+                                    int32_t *total_host, void *stream) {
   GSR_REQUIRE(n >= 0 && counts && offsets, "isect_scan_clear: bad arguments");
   hipLaunchKernelGGL(gsr::scan_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, counts,
-                     offsets, order);
+                     offsets, order, total_host);
   GSR_CHECK_LAUNCH("isect_scan_clear");
   return GSR_OK;
 }

@@ -458,17 +458,20 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
         order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
         call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), 1, st)
-        call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), st)
+        n_host = None
+        if capacity is not None:
+            # the total lands in pinned host memory straight from the scan kernel: no copy launch
+            # (and no dependent-launch gap) between scan and emit
+            n_host = _IsectState.pinned.get(dev.index)
+            if n_host is None:
+                n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), ptr(n_host), st)
         pending = None
         if capacity is None:
             n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
             cap = max(n_isects, 1)
             _IsectState.capacity[dev.index] = int(n_isects * 1.25) + 8192
         else:
-            n_host = _IsectState.pinned.get(dev.index)
-            if n_host is None:
-                n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            n_host.copy_(offsets[-1:], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             cap = max(int(capacity), 1)

@@ -168,8 +168,10 @@ int gsr_isect_count(int C, int N, const float *means2d, const int32_t *radii, in
                     void *stream);
 int gsr_isect_scan(int n_tiles, const int32_t *tile_counts, int32_t *tile_offsets,
                    int32_t *tile_order /* [n_tiles] or NULL */, void *stream);
-/* Same scan; the counts are zeroed once read (buffer reused as a cursor, kept across frames). */
-int gsr_isect_scan_clear(int n, int32_t *counts, int32_t *offsets, int32_t *order, void *stream);
+/* Same scan; the counts are zeroed once read (buffer reused as a cursor, kept across frames).
+ * total_host: NULL, or a device-accessible HOST address (pinned memory) that receives offsets[n]. */
+int gsr_isect_scan_clear(int n, int32_t *counts, int32_t *offsets, int32_t *order,
+                         int32_t *total_host, void *stream);
 int gsr_isect_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                    int tile_w, int tile_h, const int32_t *tile_offsets, int32_t *tile_cursor,
                    uint64_t *isect_keys, int64_t capacity, void *stream);
