@@ -376,17 +376,19 @@ class Metric3DNet:
         self.copy(xs, y, accumulate=True, act=ACT_RELU)              # relu(x + y)
         return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev), act=act)
 
-    def _gru(self, g, h: Map, ctx: Map, xs: List[Map]):
-        """ConvGRU.forward (decoder :318-330); h is updated in place."""
+    def _gru(self, g, h: Map, ctx: Map, xs):
+        """ConvGRU.forward (decoder :318-330); h is updated in place. xs: the inputs concatenated behind
+        h, each (channels, producer) -- the producer writes its map straight into the given channel
+        slice of the concatenated input (no copy launch per input)."""
         G = self.gru[g]
         C = G["C"]
         Cin = G["Cin"]
         hx = Map(h.H, h.W, Cin, self.dev)
         self.copy(h, hx.chan(0, C))
         c0 = C
-        for x in xs:
-            self.copy(x, hx.chan(c0, x.C))
-            c0 += x.C
+        for ch, produce in xs:
+            produce(hx.chan(c0, ch))
+            c0 += ch
         assert c0 == Cin, (g, c0, Cin)
         zr = self.conv(hx, G["zr"], 3, Map(h.H, h.W, 2 * C, self.dev))
         z = Map(h.H, h.W, C, self.dev)
@@ -396,8 +398,8 @@ class Metric3DNet:
         call("gsr_dn_gru_gate", h.P, C, 1, ptr(q.t), q.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
              None, 0, _st())
 
-    def _pool2x(self, x: Map) -> Map:
-        out = Map((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C, self.dev)
+    def _pool2x(self, x: Map, out: Optional[Map] = None) -> Map:
+        out = out if out is not None else Map((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C, self.dev)
         call("gsr_dn_avgpool3s2", x.H, x.W, x.C, ptr(x.t), x.ld, ptr(out.t), out.ld, _st())
         return out
 
@@ -464,20 +466,20 @@ class Metric3DNet:
             inter["nets"] = [Map(m.H, m.W, m.C, dev, ld=m.ld, t=m.t.clone()) for m in nets]
             inter["ctxs"] = ctxs
             inter["deltas"] = []
-        flow16 = Map(H4, W4, 6, dev)
         C2 = self.gru["gru08"]["C"]
         for _ in range(cfg["iters"]):                                          # update loop (:945-975)
-            call("gsr_dn_cvt_f32_f16", P4, 6, ptr(flow), 6, ptr(flow16.t), flow16.ld, _st())
-            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
-            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
-            self._gru("gru16", nets[1], ctxs[1],
-                      [self.resize(self._pool2x(nets[0]), H7, W7, RESIZE_BILINEAR_AC),
-                       self.resize(nets[2], H7, W7, RESIZE_BILINEAR_AC)])
-            self._gru("gru32", nets[2], ctxs[2], [self._pool2x(nets[1])])
-            self._gru("gru16", nets[1], ctxs[1],
-                      [self.resize(self._pool2x(nets[0]), H7, W7, RESIZE_BILINEAR_AC),
-                       self.resize(nets[2], H7, W7, RESIZE_BILINEAR_AC)])
-            self._gru("gru08", nets[0], ctxs[0], [flow16, self.resize(nets[1], H4, W4, RESIZE_BILINEAR_AC)])
+            Ch = [n.C for n in nets]
+            pool1 = (Ch[1], lambda dst: self._pool2x(nets[1], out=dst))              # 1/7 hidden state -> 1/14
+            up_pool0 = (Ch[0], lambda dst: self.resize(self._pool2x(nets[0]), H7, W7, RESIZE_BILINEAR_AC, out=dst))
+            up2 = (Ch[2], lambda dst: self.resize(nets[2], H7, W7, RESIZE_BILINEAR_AC, out=dst))
+            flow_in = (6, lambda dst: call("gsr_dn_cvt_f32_f16", P4, 6, ptr(flow), 6, ptr(dst.t), dst.ld, _st()))
+            up1 = (Ch[1], lambda dst: self.resize(nets[1], H4, W4, RESIZE_BILINEAR_AC, out=dst))
+            self._gru("gru32", nets[2], ctxs[2], [pool1])
+            self._gru("gru32", nets[2], ctxs[2], [pool1])
+            self._gru("gru16", nets[1], ctxs[1], [up_pool0, up2])
+            self._gru("gru32", nets[2], ctxs[2], [pool1])
+            self._gru("gru16", nets[1], ctxs[1], [up_pool0, up2])
+            self._gru("gru08", nets[0], ctxs[0], [flow_in, up1])
             # flow head (:282-297): [conv1d | conv1n] in one GEMM, then the two 3x3 output convs
             f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev), act=ACT_RELU)
             rows = self._buf("fh_rows", (P4, self.fh2d.kp))
