@@ -10,13 +10,25 @@ import json
 import shutil
 import sys
 
+import os
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: only the latest run counts."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-st = glob.glob(f"gpurun_out/{tag}_stats/*/*_kernel_stats.csv")
+st = newest(f"gpurun_out/{tag}_stats/*/*_kernel_stats.csv")
 if st:
     shutil.copy(st[0], f"profiles/{tag}_kernel_stats.csv")
+dn = newest(f"gpurun_out/{tag}_dn_stats/*/*_kernel_stats.csv")
+if dn:
+    shutil.copy(dn[0], f"profiles/{tag}_depthnet_vitl_kernel_stats.csv")
 pmc = {}
 for d in glob.glob(f"gpurun_out/{tag}_pmc_*/"):
-    for f in glob.glob(d + "*/*_counter_collection.csv"):
+    for f in newest(d + "*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
