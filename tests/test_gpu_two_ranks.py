@@ -193,3 +193,52 @@ def test_two_ranks_one_gpu_pipelined_allreduce_matches_two_camera_batch():
     for k, p in splats.items():
         ref = p.detach().cpu()
         assert torch.allclose(res[0][k], ref, rtol=1e-4, atol=1e-6), f"{k}: two ranks != two-camera batch"
+
+
+def _worker_strategy(rank, world, port, q):
+    """View-space row exchange + DefaultStrategy: refine steps (one-pass densification) and an opacity
+    reset inside the window; the fused update is suspended on those steps (runner.train_step)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+        runner, D, splats, fused, c2w, K, target = _setup()
+        sync = D.GatherRowsSync(fused, world, rank, chunks=2, min_chunk=512)
+        strat = S.DefaultStrategy(refine_start_iter=0, refine_every=3, reset_every=6, grow_grad2d=1e-5,
+                                  grow_scale3d=0.03, prune_opa=0.06)
+        state = strat.initialize_state(scene_scale=1.0)
+        strat.check_sanity(splats, fused)
+        sizes = []
+        try:
+            for step in range(1, 11):
+                cams = [D.shard_views(6, step, r, world) for r in range(world)]
+                sync.set_views(c2w[cams], K[cams])
+                cam = cams[rank]
+                runner.train_step(splats, fused, c2w[cam:cam + 1], K[cam:cam + 1], target[cam:cam + 1],
+                                  step=step, grad_sync=sync, strategy=strat, strategy_state=state)
+                sizes.append(len(splats["means"]))
+        finally:
+            sync.close()
+        torch.cuda.synchronize()
+        out = {k: p.detach().cpu().numpy() for k, p in splats.items()}
+        out["sizes"] = torch.tensor(sizes).numpy()
+        q.put((rank, out, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_replicas_stay_identical_through_densification():
+    """Two ranks, ten steps with three refine steps (duplicate / split / prune in one pass on the
+    GPU, decisions from all-reduced statistics, split noise from identically seeded generators) and
+    an opacity reset: the replicas must hold bit-identical parameters of the same, changed size."""
+    res = _run_two(_worker_strategy)
+    a, b = res[0], res[1]
+    assert torch.equal(a["sizes"], b["sizes"])
+    assert len(set(a["sizes"].tolist())) >= 3 and int(a["sizes"][-1]) != N, a["sizes"]
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
