@@ -287,7 +287,8 @@ class DefaultStrategy:
         M = n0 + n1 + 2 * n2
         src = torch.empty(M, dtype=torch.int32, device=dev)
         kind = torch.empty(M, dtype=torch.uint8, device=dev)
-        call("gsr_refine_plan", N, ptr(flags), ptr(incl), n0, n1, n2, ptr(src), ptr(kind), st)
+        if M > 0:
+            call("gsr_refine_plan", N, ptr(flags), ptr(incl), n0, n1, n2, ptr(src), ptr(kind), st)
         # the split noise: drawn for EVERY split Gaussian, in index order, as split() draws it
         samples = sel = None
         if ns > 0:
