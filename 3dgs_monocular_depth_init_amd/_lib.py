@@ -82,8 +82,8 @@ SIGNATURES.update({
     "gsr_unproject_emit": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
 })
 SIGNATURES.update({
-    "gsr_dn_gemm": [_i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p],
-    "gsr_dn_conv_gemm": [_i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p],
+    "gsr_dn_gemm": [_i, _i, _i, _p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _p],
+    "gsr_dn_conv_gemm": [_i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "gsr_dn_layernorm": [_i, _i, _p, _i, _i, _p, _p, _f, _p, _i, _p, _i, _i, _p],
     "gsr_dn_attention": [_i, _i, _i, _p, _i, _p, _f, _p, _i, _p],
     "gsr_dn_patch_rows": [_i, _i, _i, _i, _p, _p, _p],

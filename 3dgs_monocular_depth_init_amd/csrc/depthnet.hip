@@ -53,6 +53,7 @@ struct GemmArgs {
   // implicit-im2col mode (CONV): A = NHWC map [cH*cW, lda], cC channels, cKS x cKS taps, stride 1
   int cH, cW, cC, cKS, cPad;
   const h16 *zero_page;   // >= 16 bytes of zeros
+  int pad_to;             // columns [N, pad_to) of out16 are written as zeros (the map's zero channels)
 };
 
 // GELU with the erf of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding
@@ -217,7 +218,17 @@ gemm_kernel(GemmArgs p) {
   // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
   auto emit = [&](const f32x16 &a, int i, int j) {
     const int n = n0 + wn * (BNT / 2) + j * 32 + lr;
-    if (n >= p.N) return;
+    if (n >= p.N) {
+      if (n < p.pad_to) {      // zero channels of the output map, written here instead of by a fill launch
+        const int mb0 = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb0 + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) p.out16[(int64_t)m * p.ldo16 + n] = (h16)0.f;
+        }
+      }
+      return;
+    }
     const float b = p.bias ? p.bias[n] : 0.f;
     const float g = p.gamma ? p.gamma[n] : 1.f;
     const int mb = m0 + wm * 64 + i * 32 + 4 * lh;
@@ -817,7 +828,7 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
 extern "C" int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W,
                            const float *bias, int act, const float *gamma, const float *residual,
                            int ldr, const void *residual16, int ldr16, void *out16, int ldo16,
-                           float *out32, int ldo32, void *stream) {
+                           float *out32, int ldo32, int out16_pad_to, void *stream) {
   GSR_REQUIRE(M >= 0 && N >= 0 && K > 0 && K % gsr::dn::BK == 0, "dn_gemm: bad sizes M=%d N=%d K=%d (K %% 64)", M, N, K);
   if (M == 0 || N == 0) return GSR_OK;
   GSR_REQUIRE(A && W && (out16 || out32), "dn_gemm: null pointer");
@@ -831,12 +842,16 @@ extern "C" int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const vo
   p.residual16 = (const h16 *)residual16; p.ldr16 = ldr16;
   p.out16 = (h16 *)out16; p.ldo16 = ldo16; p.out32 = out32; p.ldo32 = ldo32;
   p.act = act;
+  GSR_REQUIRE(out16_pad_to <= ldo16 && (out16_pad_to <= N || out16) && out16_pad_to <= gsr::ceil_div(N, 64) * 64,
+              "dn_gemm: out16_pad_to %d (N %d, ldo16 %d)", out16_pad_to, N, ldo16);
+  p.pad_to = out16_pad_to;
   return launch_gemm<false>(p, stream);
 }
 
 extern "C" int gsr_dn_conv_gemm(int H, int Wd, int C, const void *in, int ldi, int KS, int N, int K_pad,
                                 const void *W, const float *bias, int act, const void *residual16,
-                                int ldr16, void *out16, int ldo16, const void *zero_page, void *stream) {
+                                int ldr16, void *out16, int ldo16, const void *zero_page, int out16_pad_to,
+                                void *stream) {
   GSR_REQUIRE(H > 0 && Wd > 0 && C > 0 && C % 64 == 0 && (KS == 1 || KS == 3) && N > 0 &&
                   K_pad >= KS * KS * C && K_pad % gsr::dn::BK == 0,
               "dn_conv_gemm: bad sizes H=%d W=%d C=%d (C %% 64) KS=%d K_pad=%d", H, Wd, C, KS, K_pad);
@@ -854,6 +869,9 @@ extern "C" int gsr_dn_conv_gemm(int H, int Wd, int C, const void *in, int ldi, i
   p.act = act;
   p.cH = H; p.cW = Wd; p.cC = C; p.cKS = KS; p.cPad = KS / 2;
   p.zero_page = (const h16 *)zero_page;
+  GSR_REQUIRE(out16_pad_to <= ldo16 && out16_pad_to <= gsr::ceil_div(N, 64) * 64,
+              "dn_conv_gemm: out16_pad_to %d (N %d, ldo16 %d)", out16_pad_to, N, ldo16);
+  p.pad_to = out16_pad_to;
   return launch_gemm<true>(p, stream);
 }
 

@@ -91,13 +91,16 @@ def _conv_lin(w: torch.Tensor, b, device, pad_cin: bool = True) -> _Lin:
 class Map:
     """NHWC fp16 feature map: tensor [H*W, ld] of which the first C channels are used."""
 
-    def __init__(self, H, W, C, device, ld=None, t=None):
+    def __init__(self, H, W, C, device, ld=None, t=None, zero=True):
         self.H, self.W, self.C = H, W, C
         self.ld = ld if ld is not None else _cpad(C)
-        # zpad: channels [C, ld) exist and hold zeros (allocated here; every kernel writes [0, C) only)
-        self.zpad = t is None
+        # zpad: channels [C, ld) exist and hold zeros (every kernel writes [0, C) only). zero=False:
+        # the map is about to be the output of a GEMM / convolution, which writes the zero channels
+        # itself (pad_pending) -- no fill launch per map
+        self.zpad = t is None and (zero or self.ld == C)
+        self.pad_pending = t is None and not zero and self.ld != C
         if t is None:
-            alloc = torch.empty if self.ld == C else torch.zeros
+            alloc = torch.zeros if (zero and self.ld != C) else torch.empty
             t = alloc(H * W, self.ld, dtype=torch.float16, device=device)
         self.t = t
 
@@ -231,11 +234,11 @@ class Metric3DNet:
         return t
 
     def gemm(self, M, lin: _Lin, A, lda, act=ACT_NONE, gamma=None, residual=None, ldr=0, residual16=None,
-             ldr16=0, out16=None, ldo16=0, out32=None, ldo32=0):
+             ldr16=0, out16=None, ldo16=0, out32=None, ldo32=0, pad_to=0):
         if getattr(self, "flop_count", None) is not None:
             self.flop_count += 2.0 * M * lin.n * lin.k
         call("gsr_dn_gemm", M, lin.n, lin.kp, ptr(A), lda, ptr(lin.w), ptr(lin.b), act, ptr(gamma),
-             ptr(residual), ldr, ptr(residual16), ldr16, ptr(out16), ldo16, ptr(out32), ldo32, _st())
+             ptr(residual), ldr, ptr(residual16), ldr16, ptr(out16), ldo16, ptr(out32), ldo32, pad_to, _st())
 
     def conv(self, x: Map, lin: _Lin, ks: int, out: Map, act=ACT_NONE, relu_in=False, stride=1,
              residual: Optional[Map] = None):
@@ -245,6 +248,10 @@ class Metric3DNet:
         pad = ks // 2
         Ho, Wo = (x.H + 2 * pad - ks) // stride + 1, (x.W + 2 * pad - ks) // stride + 1
         assert (Ho, Wo) == (out.H, out.W), (Ho, Wo, out.H, out.W)
+        pad_to = 0
+        if out.pad_pending:              # this launch writes the output map's zero channels
+            assert out.ld <= _ceil(lin.n, 64), (out.ld, lin.n)
+            pad_to, out.pad_pending, out.zpad = out.ld, False, True
         cin_p = getattr(lin, "cin_p", x.C)
         # channels the taps are read with: the map's own when they are a multiple of 64, else the
         # zero-padded count the weight was laid out for (the map must really hold those zeros)
@@ -256,7 +263,7 @@ class Metric3DNet:
                 self._zero_page = torch.zeros(64, dtype=torch.float16, device=self.dev)
             call("gsr_dn_conv_gemm", x.H, x.W, cC, ptr(x.t), x.ld, ks, lin.n, lin.kp, ptr(lin.w), ptr(lin.b), act,
                  None if residual is None else ptr(residual.t), 0 if residual is None else residual.ld,
-                 ptr(out.t), out.ld, ptr(self._zero_page), _st())
+                 ptr(out.t), out.ld, ptr(self._zero_page), pad_to, _st())
             return out
         assert lin.k == ks * ks * x.C, ("weight laid out for padded channels, map not eligible", lin.k, ks, x.C, x.ld)
         if ks == 1 and not relu_in and x.ld >= lin.kp and (lin.kp == lin.k or x.zpad):
@@ -267,7 +274,7 @@ class Metric3DNet:
                  int(relu_in), _st())
             A, lda = rows, lin.kp
         self.gemm(Ho * Wo, lin, A, lda, act=act, residual16=None if residual is None else residual.t,
-                  ldr16=0 if residual is None else residual.ld, out16=out.t, ldo16=out.ld)
+                  ldr16=0 if residual is None else residual.ld, out16=out.t, ldo16=out.ld, pad_to=pad_to)
         return out
 
     def resize(self, x: Map, Ho, Wo, mode, out: Optional[Map] = None) -> Map:
@@ -333,7 +340,7 @@ class Metric3DNet:
         out = Map(gh, gw, D, self.dev)
         lin = r["patch"]
         call("gsr_dn_gemm", gh * gw, lin.n, lin.kp, ptr(tokens[1 + N_REG:]), D, ptr(lin.w), ptr(bias), ACT_GELU,
-             None, None, 0, None, 0, ptr(out.t), out.ld, None, 0, _st())
+             None, None, 0, None, 0, ptr(out.t), out.ld, None, 0, 0, _st())
         return out
 
     def _conv_block(self, x: Map, c1, c2) -> Map:
@@ -342,8 +349,8 @@ class Metric3DNet:
         input rectified for every later reader -- the context encoder sees relu'd 1/14 and 1/7
         features (decoder :911-919 after :899). Reproduced, side effect included."""
         self.copy(x, x, act=ACT_RELU)
-        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev), act=ACT_RELU)     # relu(conv1(.)) in the epilogue
-        return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev), residual=x)
+        t = self.conv(x, c1, 3, Map(x.H, x.W, x.C, self.dev, zero=False), act=ACT_RELU)     # relu(conv1(.)) in the epilogue
+        return self.conv(t, c2, 3, Map(x.H, x.W, x.C, self.dev, zero=False), residual=x)
 
     def _fuse(self, name, x1: Map, x2: Optional[Map], size) -> Map:
         """FuseBlock (decoder :550-588). The 1x1 out_conv commutes with the bilinear upsampling
@@ -354,7 +361,7 @@ class Metric3DNet:
             self.copy(x1, b, accumulate=True)                         # x1 + way_branch(x2)
             x1 = b
         t = self._conv_block(x1, f["t1"], f["t2"])
-        o = self.conv(t, f["out"], 1, Map(t.H, t.W, f["out"].n, self.dev))
+        o = self.conv(t, f["out"], 1, Map(t.H, t.W, f["out"].n, self.dev, zero=False))
         if size is not None:
             o = self.resize(o, size[0], size[1], RESIZE_BILINEAR_AC)
         return o
@@ -364,17 +371,17 @@ class Metric3DNet:
         `act` = what the caller applies to the result (tanh: hidden state, ReLU: context), fused
         into the trailing convolution's epilogue."""
         C = rb["c1"].n
-        y = self.conv(x, rb["c1"], 3, Map(x.H, x.W, C, self.dev))
+        y = self.conv(x, rb["c1"], 3, Map(x.H, x.W, C, self.dev, zero=False))
         self.layernorm2d(y, rb["norm1"], relu=True)
-        y = self.conv(y, rb["c2"], 3, Map(x.H, x.W, C, self.dev))
+        y = self.conv(y, rb["c2"], 3, Map(x.H, x.W, C, self.dev, zero=False))
         self.layernorm2d(y, rb["norm2"], relu=True)
         if "ds" in rb:
-            xs = self.conv(x, rb["ds"], 1, Map(x.H, x.W, C, self.dev))
+            xs = self.conv(x, rb["ds"], 1, Map(x.H, x.W, C, self.dev, zero=False))
             self.layernorm2d(xs, rb["norm3"])
         else:
             xs = x
         self.copy(xs, y, accumulate=True, act=ACT_RELU)              # relu(x + y)
-        return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev), act=act)
+        return self.conv(y, rb["last"], 3, Map(x.H, x.W, C, self.dev, zero=False), act=act)
 
     def _gru(self, g, h: Map, ctx: Map, xs):
         """ConvGRU.forward (decoder :318-330); h is updated in place. xs: the inputs concatenated behind
@@ -390,11 +397,11 @@ class Metric3DNet:
             produce(hx.chan(c0, ch))
             c0 += ch
         assert c0 == Cin, (g, c0, Cin)
-        zr = self.conv(hx, G["zr"], 3, Map(h.H, h.W, 2 * C, self.dev))
+        zr = self.conv(hx, G["zr"], 3, Map(h.H, h.W, 2 * C, self.dev, zero=False))
         z = Map(h.H, h.W, C, self.dev)
         call("gsr_dn_gru_gate", h.P, C, 0, ptr(zr.t), zr.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
              ptr(hx.t), hx.ld, _st())                                # r*h overwrites the h slot of hx
-        q = self.conv(hx, G["q"], 3, Map(h.H, h.W, C, self.dev))
+        q = self.conv(hx, G["q"], 3, Map(h.H, h.W, C, self.dev, zero=False))
         call("gsr_dn_gru_gate", h.P, C, 1, ptr(q.t), q.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
              None, 0, _st())
 
@@ -422,7 +429,7 @@ class Metric3DNet:
             up.t[:, :4 * co].reshape(gh, gw, 2, 2, co).permute(0, 2, 1, 3, 4))
         r0 = self._readout(tokens, 0)
         # the 1x1 conv commutes with the nearest upsampling: convolve at 1/14, then replicate
-        x0s = self.conv(r0, self.read0_conv, 1, Map(gh, gw, self.read0_conv.n, dev))
+        x0s = self.conv(r0, self.read0_conv, 1, Map(gh, gw, self.read0_conv.n, dev, zero=False))
         x0 = self.resize(x0s, H4, W4, RESIZE_NEAREST)                         # 1/4, feature_channels[0]
         inter = {}
         if return_intermediates:      # copies: the fusion below rectifies x, x2, x1 in place
@@ -440,16 +447,16 @@ class Metric3DNet:
             feat = own
         P4 = H4 * W4
         # regress_depth (:806-838)
-        t = self.conv(feat, self.dreg[0], 3, Map(H4, W4, N_BINS, dev), act=ACT_RELU)
-        logits = self.conv(t, self.dreg[1], 1, Map(H4, W4, N_BINS, dev))
+        t = self.conv(feat, self.dreg[0], 3, Map(H4, W4, N_BINS, dev, zero=False), act=ACT_RELU)
+        logits = self.conv(t, self.dreg[1], 1, Map(H4, W4, N_BINS, dev, zero=False))
         flow = torch.zeros(P4, 6, dtype=torch.float32, device=dev)            # coords1 - coords0 (:925-927)
         call("gsr_dn_depth_expectation", P4, N_BINS, ptr(logits.t), logits.ld, MIN_VAL, MAX_VAL, REGRESS_SCALE,
              ptr(flow), 6, _st())
         # pred_normal (:840-850)
-        n = self.conv(feat, self.npred[0], 3, Map(H4, W4, 128, dev), act=ACT_RELU)
-        n = self.conv(n, self.npred[1], 1, Map(H4, W4, 128, dev), act=ACT_RELU)
-        n = self.conv(n, self.npred[2], 1, Map(H4, W4, 128, dev), act=ACT_RELU)
-        n = self.conv(n, self.npred[3], 1, Map(H4, W4, 3, dev))
+        n = self.conv(feat, self.npred[0], 3, Map(H4, W4, 128, dev, zero=False), act=ACT_RELU)
+        n = self.conv(n, self.npred[1], 1, Map(H4, W4, 128, dev, zero=False), act=ACT_RELU)
+        n = self.conv(n, self.npred[2], 1, Map(H4, W4, 128, dev, zero=False), act=ACT_RELU)
+        n = self.conv(n, self.npred[3], 1, Map(H4, W4, 3, dev, zero=False))
         nconf = ref_feat.chan(Cf + 1, 1)
         call("gsr_dn_normal_head", P4, ptr(n.t), n.ld, ptr(nconf.t), nconf.ld, ptr(flow[:, 2:]), 6, _st())
         flow[:, 1] = ref_feat.t[:, Cf].float()                                # depth confidence channel
@@ -459,7 +466,7 @@ class Metric3DNet:
         for lvl, src, zq in (("04", x0, self.zqr[0]), ("08", x1, self.zqr[1]), ("16", x2, self.zqr[2])):
             hnet = self._residual_block(src, self.ctx[lvl][0], act=ACT_TANH)   # net = tanh(.)
             c = self._residual_block(src, self.ctx[lvl][1], act=ACT_RELU)      # inp = relu(.)
-            ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev))                # zqr(.) -> [cz|cr|cq]
+            ctx = self.conv(c, zq, 3, Map(c.H, c.W, zq.n, dev, zero=False))                # zqr(.) -> [cz|cr|cq]
             nets.append(hnet)
             ctxs.append(ctx)
         if return_intermediates:
@@ -481,7 +488,7 @@ class Metric3DNet:
             self._gru("gru16", nets[1], ctxs[1], [up_pool0, up2])
             self._gru("gru08", nets[0], ctxs[0], [flow_in, up1])
             # flow head (:282-297): [conv1d | conv1n] in one GEMM, then the two 3x3 output convs
-            f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev), act=ACT_RELU)
+            f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev, zero=False), act=ACT_RELU)
             rows = self._buf("fh_rows", (P4, self.fh2d.kp))
             if return_intermediates:
                 before = flow.clone()
@@ -492,8 +499,8 @@ class Metric3DNet:
             if return_intermediates:
                 inter["deltas"].append(flow - before)
         # mask head of the last iteration (:309-313, 969) and convex upsampling (:870-884, 985-987)
-        m1 = self.conv(nets[0], self.mask1, 3, Map(H4, W4, C2, dev), act=ACT_RELU)
-        mask = self.conv(m1, self.mask2, 1, Map(H4, W4, self.mask2.n, dev))
+        m1 = self.conv(nets[0], self.mask1, 3, Map(H4, W4, C2, dev, zero=False), act=ACT_RELU)
+        mask = self.conv(m1, self.mask2, 1, Map(H4, W4, self.mask2.n, dev, zero=False))
         self.copy(mask, mask, a=0.25)
         Fu = 4
         depth = torch.empty(1, 1, H4 * Fu, W4 * Fu, dtype=torch.float32, device=dev)

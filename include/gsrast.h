@@ -485,16 +485,18 @@ int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_top, int pa
 /* out = residual + gamma * act(A[M,K] W[N,K]^T + bias): v_mfma_f32_32x32x16_f16, fp32 accumulate.
  * act: 0 none, 1 GELU(erf), 2 ReLU, 3 sigmoid, 4 tanh. bias/gamma [N] fp32 or NULL; residual
  * fp32 [M,ldr] and/or residual16 fp16 [M,ldr16] or NULL (may alias the outputs); out16 and/or
- * out32 receive the result. K % 64 == 0, lda >= K, lda % 8 == 0. */
+ * out32 receive the result. K % 64 == 0, lda >= K, lda % 8 == 0. out16_pad_to: 0, or the number of
+ * columns of out16 (<= ldo16, <= N rounded up to 64) of which [N, out16_pad_to) are written as
+ * zeros -- the zero channels of a map that a 3x3 convolution will read (no fill launch). */
 int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W, const float *bias, int act,
                 const float *gamma, const float *residual, int ldr, const void *residual16, int ldr16,
-                void *out16, int ldo16, float *out32, int ldo32, void *stream);
+                void *out16, int ldo16, float *out32, int ldo32, int out16_pad_to, void *stream);
 /* The same GEMM with A read as the im2col view of an NHWC fp16 map [H*W, ldi] (KS = 1 or 3,
  * stride 1, "same" padding, C % 64 == 0): row = output pixel, column = tap*C + c, gathered straight
  * from the map by the LDS-DMA staging (no im2col buffer). zero_page: >= 16 bytes of zeros. */
 int gsr_dn_conv_gemm(int H, int W, int C, const void *in, int ldi, int KS, int N, int K_pad,
                      const void *Wt, const float *bias, int act, const void *residual16, int ldr16,
-                     void *out16, int ldo16, const void *zero_page, void *stream);
+                     void *out16, int ldo16, const void *zero_page, int out16_pad_to, void *stream);
 /* LayerNorm over the last dimension of [M,D] (fp32 or fp16 input), optional ReLU. */
 int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,
                      const float *beta, float eps, void *out16, int ldo16, float *out32, int ldo32,

@@ -46,7 +46,7 @@ def _gemm(N, A, W, bias=None, act=0, gamma=None, residual=None, out32=True):
     o16 = torch.zeros(M, n, dtype=torch.float16, device="cuda")
     o32 = torch.zeros(M, n, dtype=torch.float32, device="cuda") if out32 else None
     lib.call("gsr_dn_gemm", M, n, K, A.data_ptr(), K, W.data_ptr(), lib.ptr(bias), act, lib.ptr(gamma),
-             lib.ptr(residual), n, None, 0, o16.data_ptr(), n, lib.ptr(o32), n, _st())
+             lib.ptr(residual), n, None, 0, o16.data_ptr(), n, lib.ptr(o32), n, 0, _st())
     return o16, o32
 
 
@@ -78,7 +78,7 @@ def test_gemm_epilogues_vs_torch(N):
     r = res.clone()
     lib = mod("_lib")
     lib.call("gsr_dn_gemm", M, n, K, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), 0, gamma.data_ptr(),
-             r.data_ptr(), n, None, 0, None, 0, r.data_ptr(), n, _st())    # x += gamma * (A W^T + b), in place
+             r.data_ptr(), n, None, 0, None, 0, r.data_ptr(), n, 0, _st())    # x += gamma * (A W^T + b), in place
     assert torch.allclose(r, res + gamma * z, rtol=2e-5, atol=2e-5)
 
 

@@ -37,7 +37,7 @@ def main():
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
         out = torch.empty(M, N, dtype=torch.float16, device="cuda")
         t = timeit(lambda: lib.call("gsr_dn_gemm", M, N, K, A.data_ptr(), K, W.data_ptr(), None, 0, None, None, 0,
-                                    None, 0, out.data_ptr(), N, None, 0, st))
+                                    None, 0, out.data_ptr(), N, None, 0, 0, st))
         tf = 2.0 * M * N * K / t / 1e12
         print(json.dumps({"op": "gemm", "shape": name, "M": M, "N": N, "K": K, "us": t * 1e6, "tflops": tf,
                           "frac_of_peak": tf / PEAK}), flush=True)
