@@ -138,6 +138,13 @@ def test_layernorm_conv_resize_pool_vs_torch(N):
         ref = F.relu(F.conv2d(a, wt.half().float(), bs, padding=ks // 2))[0].permute(1, 2, 0) + rin.float().view(H, W, Co)
         err = float((out.t[:, :Co].float().cpu().view(H, W, Co) - ref).abs().max())
         assert err <= 3e-3 * float(ref.abs().max()), (C, Co, ks, relu_in, err)
+        # the same launch into a map allocated WITHOUT a fill: the epilogue writes the zero channels
+        raw = N.Map(H, W, Co, "cuda", zero=False)
+        raw.t.fill_(7.0)
+        out2 = net.conv(m, N._conv_lin(wt, bs, "cuda", pad_cin=not relu_in), ks, raw, act=N.ACT_RELU, relu_in=relu_in,
+                        residual=res)
+        assert torch.equal(out2.t[:, :Co], out.t[:, :Co]) and out2.zpad and not out2.pad_pending
+        assert out2.ld == Co or float(out2.t[:, Co:].abs().max()) == 0.0
     # resize modes and pooling
     xin = torch.randn(1, 16, 11, 13, generator=g).half()
     m = N.Map(11, 13, 16, "cuda")
