@@ -47,6 +47,7 @@ SIGNATURES["gsr_l1_bwd"] = [_i64, _p, _p, _p, _f, _p, _p]
 SIGNATURES["gsr_debug_tree_reduce8"] = [_p, _p, _p, _p]
 SIGNATURES["gsr_inverse4x4"] = [_i, _p, _p, _p, _p, _p]
 SIGNATURES["gsr_pack_grad_rows"] = [_i64, _p, _p, _p, _p]
+SIGNATURES["gsr_pack_grad_rows_h"] = [_i64, _p, _p, _p, _p]
 SIGNATURES["gsr_project_bwd_adam"] = [_i, _i, _p, _p, _p, _i, _i, _f, _i, _p, _p, _i, _p, _p, _i, _i, _p,
                                       _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES["gsr_project_bwd_rows"] = [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p,

@@ -225,6 +225,22 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   for (int c = 0; c < C; ++c) {
     int64_t g = (int64_t)c * N + i;
     const float *row = grad_rows + g * row_stride;
+    float hrow[GSR_PACKED_ROW];
+    if (row_stride == GSR_PACKED_ROW_H) {   // 20-byte rows: int16 exponent + 9 halves (gsr_pack_grad_rows_h)
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(grad_rows) + g * GSR_PACKED_ROW_H;
+      const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+      const float sc = ldexpf(1.0f, (int)(int16_t)(w0 & 0xffffu));
+      const uint32_t hb[9] = {w0 >> 16, w1 & 0xffffu, w1 >> 16, w2 & 0xffffu, w2 >> 16,
+                              w3 & 0xffffu, w3 >> 16, w4 & 0xffffu, w4 >> 16};
+#pragma unroll
+      for (int k = 0; k < GSR_PACKED_ROW; ++k) {
+        const unsigned short hs = (unsigned short)hb[k];
+        _Float16 hv;
+        __builtin_memcpy(&hv, &hs, 2);
+        hrow[k] = (float)hv * sc;
+      }
+      row = hrow;
+    }
     // visibility: the radii of the pair, or (rows gathered from other ranks, packed by
     // gsr_pack_grad_rows, which zeroes the rows of invisible pairs) "the row is not all zero"
     if (radii) {
@@ -480,9 +496,9 @@ static int project_bwd_launch(int C, int N, const float *means, const float *qua
   GSR_REQUIRE(means && quats && scales && viewmats && Ks && grad_rows && v_means && v_quats &&
                   v_scales,
               "project_bwd: null pointer");
-  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW,
-              "project_bwd: grad_stride %d (16 = scratch rows, 9 = packed rows)", grad_stride);
-  GSR_REQUIRE(radii || grad_stride == GSR_PACKED_ROW,
+  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW || grad_stride == GSR_PACKED_ROW_H,
+              "project_bwd: grad_stride %d (16 = scratch rows, 9 = packed rows, 5 = half-packed rows)", grad_stride);
+  GSR_REQUIRE(radii || grad_stride != GSR_GRAD_ROW,
               "project_bwd: radii may be NULL only with packed rows (visibility from the row)");
   GSR_REQUIRE(sh_degree <= 3 && sh_K <= 16, "project_bwd: sh_degree/sh_K out of range");
   if (sh_degree >= 0)
@@ -562,6 +578,59 @@ pack_grad_rows_kernel(int64_t n, const float *__restrict__ rows, const int32_t *
 }
 }  // namespace gsr
 
+namespace gsr {
+// Half-precision form of the same rows for the exchange: 20 bytes = a shared power-of-two exponent
+// (int16; the row's largest magnitude is scaled into [0.5, 1)) and the 9 values as IEEE halves.
+// Each value keeps 11 significant bits as long as it is within 2^-14 of the row's largest -- the
+// view-space gradients reach the parameters within the 1e-3 relative tolerance BASELINE.json states,
+// with 20 instead of 36 bytes per (view, Gaussian) on the wire. Opt-in (GatherRowsSync(rows="fp16")).
+__global__ void __launch_bounds__(256)
+pack_grad_rows_h_kernel(int64_t n, const float *__restrict__ rows, const int32_t *__restrict__ radii,
+                        uint32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool vis = radii[i * 2] > 0 && radii[i * 2 + 1] > 0;
+  const float4 a = *reinterpret_cast<const float4 *>(rows + i * GSR_GRAD_ROW);
+  const float4 b = *reinterpret_cast<const float4 *>(rows + i * GSR_GRAD_ROW + 4);
+  float v[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, rows[i * GSR_GRAD_ROW + 8]};
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    v[k] = vis ? v[k] : 0.f;
+    mx = fmaxf(mx, fabsf(v[k]));
+  }
+  int e = 0;
+  if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);      // mx = f * 2^e, f in [0.5, 1)
+  e = max(-32000, min(32000, e));
+  const float inv = ldexpf(1.0f, -e);
+  uint32_t h[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const _Float16 hv = (_Float16)(v[k] * inv);
+    unsigned short hs;
+    __builtin_memcpy(&hs, &hv, 2);
+    h[k] = hs;
+  }
+  uint32_t *o = out + i * GSR_PACKED_ROW_H;
+  o[0] = ((uint32_t)(uint16_t)(int16_t)e) | (h[0] << 16);
+  o[1] = h[1] | (h[2] << 16);
+  o[2] = h[3] | (h[4] << 16);
+  o[3] = h[5] | (h[6] << 16);
+  o[4] = h[7] | (h[8] << 16);
+}
+}  // namespace gsr
+
+extern "C" int gsr_pack_grad_rows_h(int64_t n, const float *grad_rows, const int32_t *radii,
+                                    void *packed, void *stream) {
+  GSR_REQUIRE(n >= 0, "pack_grad_rows_h: bad n");
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(grad_rows && radii && packed, "pack_grad_rows_h: null pointer");
+  hipLaunchKernelGGL(gsr::pack_grad_rows_h_kernel, dim3((unsigned)gsr::ceil_div64(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, grad_rows, radii, (uint32_t *)packed);
+  GSR_CHECK_LAUNCH("pack_grad_rows_h");
+  return GSR_OK;
+}
+
 extern "C" int gsr_pack_grad_rows(int64_t n, const float *grad_rows, const int32_t *radii,
                                   float *packed, void *stream) {
   GSR_REQUIRE(n >= 0, "pack_grad_rows: bad n");
@@ -591,9 +660,9 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
   GSR_REQUIRE(viewmats && Ks && campos && grad_rows && params && exp_avg && exp_avg_sq &&
                   step_size && bc2_sqrt,
               "project_bwd_adam: null pointer");
-  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW,
-              "project_bwd_adam: grad_stride %d (16 = scratch rows, 9 = packed rows)", grad_stride);
-  GSR_REQUIRE(radii || grad_stride == GSR_PACKED_ROW,
+  GSR_REQUIRE(grad_stride == GSR_GRAD_ROW || grad_stride == GSR_PACKED_ROW || grad_stride == GSR_PACKED_ROW_H,
+              "project_bwd_adam: grad_stride %d (16 = scratch rows, 9 = packed rows, 5 = half-packed rows)", grad_stride);
+  GSR_REQUIRE(radii || grad_stride != GSR_GRAD_ROW,
               "project_bwd_adam: radii may be NULL only with packed rows (visibility flag in the row)");
   GSR_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_bwd_adam: sh_degree %d", sh_degree);
   GSR_REQUIRE(activations == (GSR_ACT_EXP_SCALES | GSR_ACT_SIGMOID_OPAC) && opacities_act,

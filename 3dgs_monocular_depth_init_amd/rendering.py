@@ -255,7 +255,7 @@ class _ProjectSH(torch.autograd.Function):
                         wait()
                         off = lambda arr: PA(*[(arr[t] or 0) + a0 * row_bytes[t] for t in range(6)])
                         call("gsr_project_bwd_adam", W, n, ptr(vm_all), ptr(Ks_all), ptr(campos_all),
-                             width, height, eps2d, sh_degree, None, ptr(rows_k), PACKED_ROW, None,
+                             width, height, eps2d, sh_degree, None, ptr(rows_k), getattr(ex, "row_stride", PACKED_ROW), None,
                              None, -1, activations, opac_act.data_ptr() + 4 * a0, off(P), off(M),
                              off(V), ss, bc2, beta1, beta2, eps, _stream())
                     return (None,) * 10
@@ -277,7 +277,7 @@ class _ProjectSH(torch.autograd.Function):
                 call("gsr_project_bwd_rows", W, n, means.data_ptr() + 12 * a0, quats.data_ptr() + 16 * a0,
                      scales.data_ptr() + 12 * a0, ptr(vm_all), ptr(Ks_all), ptr(campos_all), width,
                      height, eps2d, sh_degree, sh_a.data_ptr() + 12 * a0, 3, sh_b.data_ptr() + 180 * a0,
-                     45, None, ptr(rows_k), PACKED_ROW, v_means.data_ptr() + 12 * a0,
+                     45, None, ptr(rows_k), getattr(ex, "row_stride", PACKED_ROW), v_means.data_ptr() + 12 * a0,
                      v_quats.data_ptr() + 16 * a0, v_scales.data_ptr() + 12 * a0,
                      v_sh_a.data_ptr() + 12 * a0, 3, v_sh_b.data_ptr() + 180 * a0, 45, 16, activations,
                      opac_act.data_ptr() + 4 * a0, v_opacities.data_ptr() + 4 * a0, _stream())

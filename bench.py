@@ -337,6 +337,20 @@ def main():
         dt_o, _ = timed(3, args.steps, k_next)
         k_next += 3 + args.steps
         sync_modes[other] = {"ms_per_step": dt_o / args.steps * 1e3, "value": args.steps * world / dt_o}
+        # the opt-in 20-byte rows (shared exponent + nine halves: 11-bit view-space gradients, inside the
+        # 1e-3 tolerance of BASELINE.json but NOT the fp32 sum -- reported beside the exact modes, never as `value`)
+        if gather:
+            sync.close()
+        else:
+            rendering = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+            rendering.set_grad_arena(None)
+            optimizers.grad_sync = None
+        sync = distributed.GatherRowsSync(optimizers, world, rank, rows="fp16")
+        gather = True
+        dt_h, _ = timed(3, args.steps, k_next)
+        k_next += 3 + args.steps
+        sync_modes["gather_fp16_rows"] = {"ms_per_step": dt_h / args.steps * 1e3, "value": args.steps * world / dt_h,
+                                          "note": "reduced-precision exchange (20 B rows), reported for reference only"}
         # raw collectives on the real message sizes: bus bandwidth = 2(W-1)/W bytes / t (all-reduce),
         # (W-1)/W total bytes / t (all-gather) -- BASELINE.md section 2
         flat = torch.zeros(59 * N, dtype=torch.float32, device=dev)

@@ -49,6 +49,7 @@ extern "C" {
 #define GSR_GR_OPAC 5     /* 1: dL/d opacity                 */
 #define GSR_GR_COLOR 6    /* CH (<=5): dL/d colour channels  */
 #define GSR_GR_ABS 12     /* 2: sum |dL/d means2d| (absgrad) */
+#define GSR_PACKED_ROW_H 5 /* DWORDS of a half-packed row (gsr_pack_grad_rows_h): int16 exponent + 9 halves */
 #define GSR_PACKED_ROW 9  /* floats of a packed row (gsr_pack_grad_rows): slots 0..8 as above;  */
                           /*   an all-zero row = invisible pair (or one that contributes nothing) */
 /* `activations` bits of gsr_project_fwd/bwd: the reference's A1 step
@@ -115,6 +116,11 @@ int gsr_project_bwd(int C, int N, const float *means, const float *quats, const 
  * backward skips all-zero rows. */
 int gsr_pack_grad_rows(int64_t n, const float *grad_rows /* [n,16] */, const int32_t *radii,
                        float *packed, void *stream);
+/* The same rows in 20 bytes: a shared power-of-two exponent (int16) and the 9 values as IEEE halves
+ * (value = half * 2^exponent). Consumed by gsr_project_bwd_adam / gsr_project_bwd_rows with
+ * grad_stride = GSR_PACKED_ROW_H. Opt-in: the gradients then carry 11 significant bits. */
+int gsr_pack_grad_rows_h(int64_t n, const float *grad_rows, const int32_t *radii, void *packed,
+                         void *stream);
 
 /* gsr_project_bwd over gathered PACKED rows (grad_stride = GSR_PACKED_ROW, radii NULL:
  * visibility from the row) or scratch rows (GSR_GRAD_ROW, radii required): the non-fused

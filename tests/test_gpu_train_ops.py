@@ -458,3 +458,65 @@ def test_one_pass_refine_equals_duplicate_split_prune(step, scale2d_stop, revise
     for k in ref:
         assert got[k].shape == ref[k].shape, k
         assert torch.equal(got[k], ref[k]), k
+
+
+def test_half_packed_rows_round_trip_and_projection_backward():
+    """gsr_pack_grad_rows_h: shared exponent + 9 halves. (a) decoding the 20-byte rows on the host
+    reproduces the fp32 packed rows to 2^-11 of each row's largest value, exactly zero for
+    invisible pairs; (b) the projection backward fed with half rows (grad_stride 5) equals the one
+    fed with fp32 packed rows to 1e-3 relative (L2) per gradient tensor."""
+    import numpy as np
+    lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    from tests import scenes
+    g = torch.Generator().manual_seed(9)
+    n = 5000
+    rows = torch.zeros(n, 16)
+    rows[:, :9] = torch.randn(n, 9, generator=g) * torch.exp(torch.randn(n, 1, generator=g) * 6.0)   # 1e-8 .. 1e8
+    rows[::7, :9] *= torch.tensor([1e-5, 1.0, 1e3, 1.0, 1e-3, 1.0, 1.0, 10.0, 0.1])
+    radii = torch.randint(0, 3, (n, 2), generator=g).to(torch.int32)
+    rows_d, radii_d = rows.cuda(), radii.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    p32 = torch.empty(n, 9, device="cuda")
+    p16 = torch.empty(n, 5, dtype=torch.int32, device="cuda")
+    lib.call("gsr_pack_grad_rows", n, rows_d.data_ptr(), radii_d.data_ptr(), p32.data_ptr(), st)
+    lib.call("gsr_pack_grad_rows_h", n, rows_d.data_ptr(), radii_d.data_ptr(), p16.data_ptr(), st)
+    raw = p16.cpu().numpy().view(np.uint16).reshape(n, 10)
+    exp = raw[:, 0].view(np.int16).astype(np.float64)
+    dec = raw[:, 1:].copy().view(np.float16).astype(np.float64) * (2.0 ** exp)[:, None]
+    ref = p32.cpu().double().numpy()
+    vis = ((radii > 0).all(1)).numpy()
+    assert np.all(dec[~vis] == 0) and np.all(ref[~vis] == 0)
+    mx = np.abs(ref).max(1, keepdims=True)
+    assert np.all(np.abs(dec - ref) <= mx * 2.0 ** -11 + 1e-300)
+    # (b) through the projection backward
+    N = 4096
+    sc = scenes.make_scene(N, 4, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    vm, K = scenes.cameras([0, 7], width=96, height=64, f=90.0, dist=2.5)
+    vm, K = vm.cuda().contiguous(), K.cuda().contiguous()
+    campos = torch.linalg.inv(vm)[:, :3, 3].contiguous()
+    means, quats = sc["means"].cuda(), sc["quats"].cuda()
+    scales, shN, sh0 = torch.log(sc["scales"]).cuda(), sc["shN"].cuda().contiguous(), sc["sh0"].cuda().contiguous()
+    opac_act = sc["opacities"].cuda()
+    big = torch.zeros(2 * N, 16)
+    big[:, :9] = torch.randn(2 * N, 9, generator=g) * 1e-3
+    vis2 = torch.ones(2 * N, 2, dtype=torch.int32)
+    vis2[::5] = 0
+    a32 = torch.empty(2 * N, 9, device="cuda")
+    a16 = torch.empty(2 * N, 5, dtype=torch.int32, device="cuda")
+    lib.call("gsr_pack_grad_rows", 2 * N, big.cuda().data_ptr(), vis2.cuda().data_ptr(), a32.data_ptr(), st)
+    lib.call("gsr_pack_grad_rows_h", 2 * N, big.cuda().data_ptr(), vis2.cuda().data_ptr(), a16.data_ptr(), st)
+
+    def bwd(packed, stride):
+        outs = [torch.zeros(N, 3, device="cuda"), torch.zeros(N, 4, device="cuda"), torch.zeros(N, 3, device="cuda"),
+                torch.zeros(N, 1, 3, device="cuda"), torch.zeros(N, 15, 3, device="cuda"), torch.zeros(N, device="cuda")]
+        lib.call("gsr_project_bwd_rows", 2, N, means.data_ptr(), quats.data_ptr(), scales.data_ptr(), vm.data_ptr(),
+                 K.data_ptr(), campos.data_ptr(), 96, 64, 0.3, 3, sh0.data_ptr(), 3, shN.data_ptr(), 45, None,
+                 packed.data_ptr(), stride, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                 outs[3].data_ptr(), 3, outs[4].data_ptr(), 45, 16, 3, opac_act.data_ptr(), outs[5].data_ptr(), st)
+        torch.cuda.synchronize()
+        return outs
+
+    r32, r16 = bwd(a32, 9), bwd(a16, 5)
+    for x, y in zip(r32, r16):
+        assert float(x.norm()) > 0
+        assert float((x - y).norm() / x.norm()) <= 1e-3

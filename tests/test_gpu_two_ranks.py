@@ -39,7 +39,7 @@ def _setup():
     return runner, D, splats, D.fuse_optimizers(splats, opts), c2w, K, target
 
 
-def _worker_gather(rank, world, port, q, chunks=3):
+def _worker_gather(rank, world, port, q, chunks=3, rows="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -47,7 +47,7 @@ def _worker_gather(rank, world, port, q, chunks=3):
     try:
         runner, D, splats, fused, c2w, K, target = _setup()
         # 3 pipelined Gaussian ranges (boundaries on multiples of 64, the last one ragged)
-        sync = D.GatherRowsSync(fused, world, rank, chunks=chunks, min_chunk=512)
+        sync = D.GatherRowsSync(fused, world, rank, chunks=chunks, min_chunk=512, rows=rows)
         assert len(sync.chunk_bounds(N)) == chunks
         try:
             for step in range(3):
@@ -141,6 +141,29 @@ def test_two_ranks_gathered_view_space_rows_match_two_camera_batch():
 
 def _worker_gather_monolithic(rank, world, port, q):
     _worker_gather(rank, world, port, q, chunks=1)
+
+
+def _worker_gather_fp16(rank, world, port, q):
+    _worker_gather(rank, world, port, q, chunks=3, rows="fp16")
+
+
+def test_two_ranks_half_precision_rows_within_tolerance():
+    """GatherRowsSync(rows="fp16"): the rows travel as a shared exponent + nine IEEE halves (20 bytes
+    instead of 36). Replicas stay bit-identical (every rank decodes the same bytes). Against the
+    fp32 exchange, three Adam steps from fresh moments move every parameter by about lr per step
+    whatever the gradient's size (m / sqrt(v) is +-1 at first), so a value that 11-bit rows round
+    differently can shift a parameter by a fraction of lr, and a gradient at the edge of the half
+    range (Adam turns even a 1e-12 gradient into a full step, eps = 1e-15) by a whole one: the bar is
+    1 % of the three-step travel in the mean and at most one element in a thousand off by more than 10 %."""
+    half = _run_two(_worker_gather_fp16)
+    full = _run_two(_worker_gather)
+    lrs = {"means": 1.6e-4, "scales": 5e-3, "quats": 1e-3, "opacities": 5e-2, "sh0": 2.5e-3, "shN": 2.5e-3 / 20}
+    for k in half[0]:
+        assert torch.equal(half[0][k], half[1][k]), f"replicas diverged in {k}"
+        travel = 3 * lrs[k] * 2 ** 0.5                       # lr is scaled by sqrt(batch size 2)
+        d = (half[0][k] - full[0][k]).abs()
+        frac = float((d > 0.1 * travel).float().mean())
+        assert float(d.mean()) <= 0.01 * travel and frac <= 1e-3, (k, float(d.max()), float(d.mean()), frac)
 
 
 def test_pipelined_row_exchange_equals_monolithic_exchange():
