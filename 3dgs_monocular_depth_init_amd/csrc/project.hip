@@ -225,7 +225,8 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   for (int c = 0; c < C; ++c) {
     int64_t g = (int64_t)c * N + i;
     const float *row = grad_rows + g * row_stride;
-    float hrow[GSR_PACKED_ROW];
+    // the 9 used values of the row, from whichever format it travels in
+    float rv[GSR_PACKED_ROW];
     if (row_stride == GSR_PACKED_ROW_H) {   // 20-byte rows: int16 exponent + 9 halves (gsr_pack_grad_rows_h)
       const uint32_t *w = reinterpret_cast<const uint32_t *>(grad_rows) + g * GSR_PACKED_ROW_H;
       const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
@@ -237,9 +238,11 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         const unsigned short hs = (unsigned short)hb[k];
         _Float16 hv;
         __builtin_memcpy(&hv, &hs, 2);
-        hrow[k] = (float)hv * sc;
+        rv[k] = (float)hv * sc;
       }
-      row = hrow;
+    } else {
+#pragma unroll
+      for (int k = 0; k < GSR_PACKED_ROW; ++k) rv[k] = row[k];
     }
     // visibility: the radii of the pair, or (rows gathered from other ranks, packed by
     // gsr_pack_grad_rows, which zeroes the rows of invisible pairs) "the row is not all zero"
@@ -248,21 +251,21 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     } else {
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < GSR_PACKED_ROW; ++k) any |= (row[k] != 0.f);
+      for (int k = 0; k < GSR_PACKED_ROW; ++k) any |= (rv[k] != 0.f);
       if (!any) continue;
     }
-    v_op += row[GSR_GR_OPAC];
-    float v_m2d[2] = {row[GSR_GR_MEAN2D], row[GSR_GR_MEAN2D + 1]};
-    float v_con[3] = {row[GSR_GR_CONIC], row[GSR_GR_CONIC + 1], row[GSR_GR_CONIC + 2]};
+    v_op += rv[GSR_GR_OPAC];
+    float v_m2d[2] = {rv[GSR_GR_MEAN2D], rv[GSR_GR_MEAN2D + 1]};
+    float v_con[3] = {rv[GSR_GR_CONIC], rv[GSR_GR_CONIC + 1], rv[GSR_GR_CONIC + 2]};
     float v_depth = 0.f;
     if (v_depths) v_depth += v_depths[g];
-    if (depth_channel >= 0) v_depth += row[GSR_GR_COLOR + depth_channel];
+    if (depth_channel >= 0) v_depth += row[GSR_GR_COLOR + depth_channel];   // (fp32 scratch rows only)
     float v_comp = v_comps ? v_comps[g] : 0.f;
     gs::Camera cam = gs::load_camera(viewmats + c * 16, Ks + c * 9);
     gs::project_ewa_vjp(cam, mean, covar, width, height, eps2d, v_m2d, v_depth, v_con, v_comp,
                         v_mean, v_covar);
     if (sh_degree >= 0) {
-      float v_col[3] = {row[GSR_GR_COLOR], row[GSR_GR_COLOR + 1], row[GSR_GR_COLOR + 2]};
+      float v_col[3] = {rv[GSR_GR_COLOR], rv[GSR_GR_COLOR + 1], rv[GSR_GR_COLOR + 2]};
       float dx = mean[0] - campos[c * 3 + 0];
       float dy = mean[1] - campos[c * 3 + 1];
       float dz = mean[2] - campos[c * 3 + 2];

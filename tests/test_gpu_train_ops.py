@@ -503,8 +503,9 @@ def test_half_packed_rows_round_trip_and_projection_backward():
     vis2[::5] = 0
     a32 = torch.empty(2 * N, 9, device="cuda")
     a16 = torch.empty(2 * N, 5, dtype=torch.int32, device="cuda")
-    lib.call("gsr_pack_grad_rows", 2 * N, big.cuda().data_ptr(), vis2.cuda().data_ptr(), a32.data_ptr(), st)
-    lib.call("gsr_pack_grad_rows_h", 2 * N, big.cuda().data_ptr(), vis2.cuda().data_ptr(), a16.data_ptr(), st)
+    big_d, vis_d = big.cuda(), vis2.cuda()        # (kept alive: the launches are asynchronous)
+    lib.call("gsr_pack_grad_rows", 2 * N, big_d.data_ptr(), vis_d.data_ptr(), a32.data_ptr(), st)
+    lib.call("gsr_pack_grad_rows_h", 2 * N, big_d.data_ptr(), vis_d.data_ptr(), a16.data_ptr(), st)
 
     def bwd(packed, stride):
         outs = [torch.zeros(N, 3, device="cuda"), torch.zeros(N, 4, device="cuda"), torch.zeros(N, 3, device="cuda"),
