@@ -156,6 +156,37 @@ def test_tiny_rgb_ed_with_background(R):
     _check(*_run_both(R, sc, vm, K, W, H, render_mode="RGB+ED", backgrounds=bg), img_atol=5e-4)
 
 
+@pytest.mark.parametrize("render_mode", ["D", "ED", "RGB+D"])
+def test_tiny_depth_render_modes(R, render_mode):
+    """The depth-carrying render modes of gsplat's rasterization(): accumulated depth (D), expected
+    depth (ED = D / alpha) alone and beside the colours; gradients flow to the means through the depth."""
+    sc, vm, K, W, H = _tiny()
+    _check(*_run_both(R, sc, vm, K, W, H, render_mode=render_mode), img_atol=5e-4)
+
+
+def test_tiny_precomputed_colors_and_two_camera_antialiased(R):
+    """colors given per Gaussian ([N,3], sh_degree=None) instead of SH coefficients, two cameras,
+    antialiased compensation: the non-SH input path (`gsr_pack_records`) against the oracle."""
+    sc = scenes.make_scene(700, 12, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    vm, K = scenes.cameras([3, 40], width=80, height=56, f=85.0, dist=2.5)
+    col = torch.rand(700, 3, generator=torch.Generator().manual_seed(4))
+    names = ["means", "quats", "scales", "opacities"]
+    cpu = {k: sc[k].clone().requires_grad_(True) for k in names}
+    gpu = {k: sc[k].clone().cuda().requires_grad_(True) for k in names}
+    cpu["colors"], gpu["colors"] = col.clone().requires_grad_(True), col.clone().cuda().requires_grad_(True)
+    rc_c, ra_c, meta_c = O.rasterization(cpu["means"], cpu["quats"], cpu["scales"], cpu["opacities"], cpu["colors"],
+                                         vm, K, 80, 56, sh_degree=None, rasterize_mode="antialiased")
+    rc_g, ra_g, meta_g = R.rasterization(gpu["means"], gpu["quats"], gpu["scales"], gpu["opacities"], gpu["colors"],
+                                         vm.cuda(), K.cuda(), 80, 56, sh_degree=None, packed=False,
+                                         rasterize_mode="antialiased")
+    g = torch.Generator().manual_seed(21)
+    w_c, w_a = torch.randn(rc_c.shape, generator=g), torch.randn(ra_c.shape, generator=g)
+    ((rc_c * w_c).sum() + (ra_c * w_a).sum()).backward()
+    ((rc_g * w_c.cuda()).sum() + (ra_g * w_a.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    _check(cpu, gpu, (rc_c, ra_c, meta_c), (rc_g, ra_g, meta_g))
+
+
 def test_tiny_antialiased(R):
     sc, vm, K, W, H = _tiny()
     _check(*_run_both(R, sc, vm, K, W, H, rasterize_mode="antialiased"))
