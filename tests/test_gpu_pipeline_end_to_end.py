@@ -1,0 +1,116 @@
+"""The whole hot path in one piece, as a user of the reference would run it: monocular-depth
+initialisation (depth predictor -> SfM reprojection -> RANSAC scale/shift alignment -> subsampling
+-> unprojection -> kNN scales) feeding `create_splats_with_optimizers`, then the training loop
+(rasterize -> L1 + SSIM -> backward -> DefaultStrategy -> fused Adam). Synthetic: the target images
+and the "predicted" depth come from a ground-truth Gaussian scene rendered by the same rasterizer;
+the predictor hands out an affinely distorted depth (as a monocular network would), which the
+alignment has to undo from a few hundred SfM points."""
+import importlib
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+P_ = "3dgs_monocular_depth_init_amd."
+
+
+def test_depth_init_then_training():
+    from tests import scenes
+    runner = importlib.import_module(P_ + "runner")
+    optim = importlib.import_module(P_ + "optim")
+    S = importlib.import_module(P_ + "strategy")
+    MDI = importlib.import_module(P_ + "monocular_depth_init")
+    cfgm = importlib.import_module(P_ + "config")
+    dac = importlib.import_module(P_ + "depth_alignment.config")
+    ifc = importlib.import_module(P_ + "depth_prediction.predictors.depth_predictor_interface")
+    torch.manual_seed(0)
+    W, H, n_cam = 160, 120, 8
+    gt = scenes.make_scene(4000, 21, box=(1.0, 0.7, 0.25), scale_mean=0.035)
+    gt["opacities"] = gt["opacities"].clamp_min(0.6)                  # a mostly opaque slab: depth is well defined
+    vms, Ks = scenes.cameras(range(0, 96, 12), width=W, height=H, f=150.0, dist=2.5)
+    c2ws, Ks = torch.linalg.inv(vms).contiguous().cuda(), Ks.cuda()
+    gt_splats, _ = runner.create_splats_with_optimizers(
+        gt["means"], torch.rand(4000, 3), torch.log(gt["scales"]), quats=gt["quats"],
+        opacities_logit=torch.logit(gt["opacities"]), shN=gt["shN"])
+    with torch.no_grad():
+        gt_splats["sh0"].copy_(gt["sh0"].cuda())
+        targets, depths, alphas = [], [], []
+        for i in range(n_cam):
+            rc, ra, _ = runner.rasterize_splats(gt_splats, c2ws[i:i + 1], Ks[i:i + 1], W, H, sh_degree=3,
+                                                render_mode="RGB+ED")
+            targets.append(rc[..., :3].clamp(0, 1))
+            depths.append(rc[0, ..., 3])
+            alphas.append(ra[0, ..., 0])
+
+    class FakeMonocularNet:               # depth up to an affine map, like a monocular predictor's output
+        name = "fake"
+
+        def __init__(self):
+            self.i = 0
+
+        def predict_depth(self, image, intrinsics):
+            d, a = depths[self.i], alphas[self.i]
+            self.i += 1
+            return ifc.PredictedDepth(depth=((d - 0.3) / 1.8).contiguous(), mask=(a > 0.9).contiguous())
+
+    # SfM points: 400 points per image on the visible surface (pixels of the GT depth map unprojected),
+    # 15 % of them with a gross depth error, as triangulated points have
+    frames = []
+    g = torch.Generator().manual_seed(3)
+    for i in range(n_cam):
+        ys, xs = torch.nonzero(alphas[i].cpu() > 0.95, as_tuple=True)
+        sel = torch.randperm(ys.numel(), generator=g)[:400]
+        x, y = xs[sel].float(), ys[sel].float()
+        z = depths[i].cpu()[ys[sel], xs[sel]]
+        bad = torch.rand(400, generator=g) < 0.15
+        z = torch.where(bad, z * (0.5 + torch.rand(400, generator=g)), z)
+        Kc = Ks[i].cpu()
+        cam = torch.stack([(x - Kc[0, 2]) / Kc[0, 0] * z, (y - Kc[1, 2]) / Kc[1, 1] * z, z], 1)
+        world = cam @ c2ws[i].cpu()[:3, :3].T + c2ws[i].cpu()[:3, 3]
+        frames.append(MDI.Frame(image=(targets[i][0] * 255.0).contiguous(), image_name=f"im{i}", camtoworld=c2ws[i].cpu(),
+                                K=Kc, sfm_points=world.cuda()))
+    cfg = cfgm.Config()
+    cfg.mdi.alignment.aligner = dac.DepthAlignmentStrategyEnum.ransac
+    cfg.mdi.subsample_factor = 3
+    cfg.mdi.limit_init_scale = True
+    pts, rgbs, scales = MDI.pts_and_rgb_from_frames(cfg, frames, FakeMonocularNet(), "cuda:0")
+    assert pts.shape[0] > 3000 and rgbs.shape == pts.shape and scales.shape == pts.shape
+    # the alignment undid the affine distortion: the points lie on the GT surface -- their depth in camera 0
+    # against the GT depth map at their pixel (points of all cameras, those that project into camera 0)
+    w2c = torch.linalg.inv(c2ws[0])
+    cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
+    uv = cam[:, :2] / cam[:, 2:3] * torch.stack([Ks[0, 0, 0], Ks[0, 1, 1]]) + torch.stack([Ks[0, 0, 2], Ks[0, 1, 2]])
+    px, py = uv[:, 0].round().long(), uv[:, 1].round().long()
+    inside = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (cam[:, 2] > 0)
+    ref = depths[0][py[inside], px[inside]]
+    ok = alphas[0][py[inside], px[inside]] > 0.9
+    rel = ((cam[inside, 2] - ref).abs() / ref)[ok]
+    assert int(ok.sum()) > 1000 and float(rel.median()) < 0.03, float(rel.median())
+
+    # training from that initialisation
+    splats, opts = runner.create_splats_with_optimizers(pts.cpu(), rgbs.cpu(), scales.cpu(), init_opacity=0.3)
+    fused = optim.FusedAdam(opts)
+    fused.fuse_into_backward(True)
+    strat = S.DefaultStrategy(refine_start_iter=20, refine_every=25, reset_every=10_000, refine_stop_iter=500,
+                              grow_grad2d=1e-4)
+    strat.check_sanity(splats, fused)
+    st = strat.initialize_state(scene_scale=1.0)
+    losses, sizes = [], []
+    try:
+        for step in range(151):
+            i = step % n_cam
+            loss, _ = runner.train_step(splats, fused, c2ws[i:i + 1], Ks[i:i + 1], targets[i], step=step,
+                                        ssim_lambda=0.2, strategy=strat, strategy_state=st)
+            losses.append(float(loss))
+            sizes.append(len(splats["means"]))
+    finally:
+        fused.fuse_into_backward(False)
+    assert all(math.isfinite(x) for x in losses)
+    first, last = sum(losses[:8]) / 8, sum(losses[-8:]) / 8
+    assert last < 0.6 * first, (first, last)
+    assert sizes[-1] != sizes[0]
+    with torch.no_grad():
+        rc, _, _ = runner.rasterize_splats(splats, c2ws[:1], Ks[:1], W, H, sh_degree=3)
+        mse = float(((rc.clamp(0, 1) - targets[0]) ** 2).mean())
+    assert -10.0 * math.log10(mse) > 20.0, -10.0 * math.log10(mse)
