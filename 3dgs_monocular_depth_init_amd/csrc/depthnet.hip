@@ -249,6 +249,191 @@ gemm_kernel(GemmArgs p) {
     for (int j = 0; j < NJ; ++j) emit(acc[i][j], i, j);
 }
 
+// ---- 256x256x64 tile, two wave groups in ping-pong -----------------------------------------------
+// The 128-wide tiles above read as many LDS bytes per MFMA as the LDS can deliver (a 64x64 wave tile
+// needs 16 KB of fragments per 16 MFMAs: 1024 LDS cycles per CU against 1024 MFMA cycles per SIMD), so
+// they top out near 30 % of the MFMA peak. Here a wave owns 128x64 outputs (24 KB of fragments per
+// 32 MFMAs: ratio 0.75) and the eight waves of the workgroup run as two groups of four -- group g =
+// the upper / lower 128 rows, one wave of each group per SIMD -- offset by one barrier interval:
+// while one group issues its 32 MFMAs of a K-tile, the other reads the next K-tile's fragments from
+// LDS into registers, so neither the LDS latency nor the barrier is exposed to the matrix pipe.
+//   slot 2u   : group 0 LOAD(u) (+ issues the LDS-DMA of tile u+1) | group 1 MFMA(u-1) (+ DMA of tile u+1)
+//   slot 2u+1 : group 0 MFMA(u)                                   | group 1 LOAD(u)
+// Tile u lives in buffer u & 1. Its DMA is issued in slot 2u-2 (after the last reads of tile u-2, which
+// end with slot 2u-3), every wave waits for its own DMA (vmcnt(0)) before the barrier that ends slot
+// 2u-1, and the first read is in slot 2u: the wait-then-barrier order the LDS-DMA needs. Group 1 takes
+// one barrier more at the start, group 0 one more at the end: equal counts.
+constexpr int BM2 = 256, BN2 = 256;
+template <int ACT, bool CONV>
+__global__ void __launch_bounds__(512)
+gemm256_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM2 + BN2) * BK];   // 2 x 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wc = wave & 3;
+  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
+  int wg = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
+    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+  }
+  const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // staging: wave w, instruction i moves rows (4w + i)*8 .. +7 of A and of B; lane -> (row, physical chunk)
+  const int srow = lane >> 3, pch = lane & 7;
+  const h16 *ga[4], *gb[4];
+  int pix_y[4], pix_x[4], lch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + srow;
+    lch[i] = (pch ^ ((r >> 1) & 7)) * 8;
+    const int m = min(m0 + r, p.M - 1);
+    if (CONV) {
+      pix_y[i] = m / p.cW;
+      pix_x[i] = m - pix_y[i] * p.cW;
+      ga[i] = nullptr;
+    } else {
+      ga[i] = p.A + (int64_t)m * p.lda + lch[i];
+    }
+    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto stage = [&](int buf, int k0) {
+    int ky = 0, kx = 0, c0 = 0;
+    bool tap_ok = true;
+    if (CONV) {
+      const int tap = k0 / p.cC;
+      c0 = k0 - tap * p.cC;
+      ky = tap / p.cKS;
+      kx = tap - ky * p.cKS;
+      tap_ok = tap < p.cKS * p.cKS;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const h16 *src;
+      if (CONV) {
+        const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
+        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
+      } else {
+        src = ga[i] + k0;
+      }
+      h16 *dA = &smem[buf][(wave * 4 + i) * 8 * BK];
+      h16 *dB = &smem[buf][BM2 * BK + (wave * 4 + i) * 8 * BK];
+      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dA, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + k0), (lds_void *)dB, 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  half8 af[4][4], bf[2][4];   // [tile][k-step]
+
+  auto load_frags = [&](int buf) {
+    const h16 *sA = smem[buf], *sB = smem[buf] + BM2 * BK;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int cl = 2 * s + lh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = grp * 128 + i * 32 + lr;
+        af[i][s] = *reinterpret_cast<const half8 *>(sA + ra * BK + ((cl ^ ((ra >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = wc * 64 + j * 32 + lr;
+        bf[j][s] = *reinterpret_cast<const half8 *>(sB + rb * BK + ((cl ^ ((rb >> 1) & 7)) << 3));
+      }
+    }
+  };
+  auto mfma_tile = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define GSR_SLOT_END()                              \
+  __builtin_amdgcn_sched_barrier(0);                \
+  __builtin_amdgcn_s_barrier();                     \
+  __builtin_amdgcn_sched_barrier(0)
+#define GSR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GSR_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  GSR_WAIT_DMA();
+  GSR_SLOT_END();                                  // tile 0 is in LDS for everyone
+  if (grp == 0) {
+    for (int u = 0; u < nk; ++u) {
+      if (u + 1 < nk) stage((u + 1) & 1, (u + 1) * BK);     // slot 2u: LOAD(u)
+      load_frags(u & 1);
+      GSR_WAIT_LDS();
+      GSR_SLOT_END();
+      mfma_tile();                                           // slot 2u+1: MFMA(u)
+      GSR_WAIT_DMA();
+      GSR_SLOT_END();
+    }
+    GSR_SLOT_END();                                          // (group 1's last MFMA slot)
+  } else {
+    if (1 < nk) stage(1, BK);                                // slot 0: this group's share of tile 1
+    GSR_SLOT_END();
+    for (int u = 0; u < nk; ++u) {
+      load_frags(u & 1);                                     // slot 2u+1: LOAD(u)
+      GSR_WAIT_LDS();
+      GSR_WAIT_DMA();
+      GSR_SLOT_END();
+      if (u + 2 < nk) stage(u & 1, (u + 2) * BK);            // slot 2u+2: MFMA(u), DMA of tile u+2
+      mfma_tile();
+      GSR_SLOT_END();
+    }
+  }
+#undef GSR_SLOT_END
+#undef GSR_WAIT_DMA
+#undef GSR_WAIT_LDS
+
+  // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + lr;
+      const int mb = m0 + grp * 128 + i * 32 + 4 * lh;
+      if (n >= p.N) {
+        if (n < p.pad_to) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < p.M) p.out16[(int64_t)m * p.ldo16 + n] = (h16)0.f;
+          }
+        }
+        continue;
+      }
+      const float b = p.bias ? p.bias[n] : 0.f;
+      const float g = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float v = act_fn<ACT>(acc[i][j][r] + b) * g;
+        if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+        if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
+        if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
+        if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
+      }
+    }
+}
+
 // ---- LayerNorm over the last dimension: one wave per row, fp32 statistics -------------------
 template <typename TIN>
 __global__ void __launch_bounds__(256)
@@ -803,6 +988,24 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   const int b128 = rows * gsr::ceil_div(p.N, 128), b64 = rows * gsr::ceil_div(p.N, 64);
   // (only where the rounding matters, up to two rounds: 8192^3 is 1390 us wide, 1560 us narrow)
   const bool narrow = p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512);
+  // 256x256 ping-pong tile where its grid fills the chip: one round of 192..256 workgroups (one per CU),
+  // or many rounds. Measured: 4096^3 739 -> 950 TFLOP/s, 8192^3 800 -> 966, the 3349 x 4096 x 1024 MLP
+  // GEMM (224 workgroups) 61 -> 54 us; 168 workgroups (QKV) or 56 (N = 1024) lose to the narrow tiles.
+  const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
+  if (p.K >= 512 && ((b256 >= 192 && b256 <= 256) || b256 >= 768)) {
+    const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
+#define GSR_GEMM2(A) hipLaunchKernelGGL((gemm256_kernel<A, CONV>), grid, dim3(512), 0, st, p)
+    switch (p.act) {
+      case ACT_GELU: GSR_GEMM2(ACT_GELU); break;
+      case ACT_RELU: GSR_GEMM2(ACT_RELU); break;
+      case ACT_SIGMOID: GSR_GEMM2(ACT_SIGMOID); break;
+      case ACT_TANH: GSR_GEMM2(ACT_TANH); break;
+      default: GSR_GEMM2(ACT_NONE); break;
+    }
+#undef GSR_GEMM2
+    GSR_CHECK_LAUNCH("dn_gemm256");
+    return GSR_OK;
+  }
 #define GSR_GEMM(A, BNT_)                                                                             \
   hipLaunchKernelGGL((gemm_kernel<A, CONV, BNT_>), dim3((unsigned)gsr::ceil_div(p.N, BNT_), (unsigned)rows), \
                      dim3(256), 0, st, p)

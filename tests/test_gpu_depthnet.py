@@ -50,8 +50,10 @@ def _gemm(N, A, W, bias=None, act=0, gamma=None, residual=None, out32=True):
     return o16, o32
 
 
+# (3349, 4096, 1024) and (3900, 3900, 576) take the 256x256 ping-pong kernel (224 / 256 workgroups, ragged
+# edges in M and N, odd and even K-tile counts), the others the 128-row tiles in both widths
 @pytest.mark.parametrize("M,n,K", [(3349, 1152, 384), (3349, 1024, 4096), (1, 384, 1920), (200, 258, 512),
-                                   (40964, 256, 2304), (130, 6, 448)])
+                                   (40964, 256, 2304), (130, 6, 448), (3349, 4096, 1024), (3900, 3900, 576)])
 def test_gemm_vs_torch(N, M, n, K):
     g = torch.Generator().manual_seed(M + n + K)
     A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
