@@ -10,7 +10,14 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SIMDS = 1024
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"gpurun_out/{tag}_dnpmc_*/*/*_counter_collection.csv"):
+import os
+
+files = []
+for d in glob.glob(f"gpurun_out/{tag}_dnpmc_*/"):          # gpurun merges every call into the same directories:
+    cand = glob.glob(d + "*/*_counter_collection.csv")      # only the latest run of each pass counts
+    if cand:
+        files.append(max(cand, key=os.path.getmtime))
+for f in files:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0]
         if "gsr::dn" not in name and "gsr2dn" not in name:
