@@ -31,7 +31,9 @@ def main():
     shapes = [(3349, 3072, 1024, "vitl qkv"), (3349, 1024, 1024, "vitl proj"), (3349, 4096, 1024, "vitl fc1"),
               (3349, 1024, 4096, "vitl fc2"), (3349, 1152, 384, "vits qkv"), (3349, 1536, 384, "vits fc1"),
               (4096, 4096, 4096, "4096^3"), (8192, 8192, 8192, "8192^3"), (40964, 256, 2304, "conv 1/4 256->256"),
-              (13376, 512, 4608, "conv 1/7 512->512"), (3344, 1024, 9216, "conv 1/14 1024->1024")]
+              (13376, 512, 4608, "conv 1/7 512->512"), (3344, 1024, 9216, "conv 1/14 1024->1024"),
+              (40964, 512, 2880, "gru08 zr 320->512 @1/4"), (40964, 256, 2880, "gru08 q 320->256 @1/4"),
+              (13376, 512, 3456, "conv 1/7 384->512"), (40964, 256, 1152, "conv 1/4 128->256")]
     for M, N, K, name in shapes:
         A = (torch.randn(M, K, device="cuda") * 0.5).half()
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
