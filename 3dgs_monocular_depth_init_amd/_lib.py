@@ -172,6 +172,14 @@ def kernel_times_ms() -> dict:
     return out
 
 
+def current_stream() -> int:
+    """Raw handle of torch's current HIP stream (the kernels are launched on it). One C call:
+    `torch.cuda.current_stream().cuda_stream` builds a Stream object each time (~10 us, and a
+    step issues ~20 launches)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
 def ptr(t) -> int | None:
     """data_ptr of a tensor or None."""
     return None if t is None else t.data_ptr()

@@ -16,6 +16,7 @@ import ctypes as C
 import torch
 from torch import Tensor
 
+from ._lib import current_stream as _raw_stream
 from ._lib import call, ptr
 
 
@@ -24,7 +25,7 @@ def _strides(t: Tensor):
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 _SSIM_WS = {}    # (device index, shape) -> per-workgroup partial sums of the forward

@@ -206,8 +206,20 @@ class FusedAdam:
         return PA(*ps), PA(*ms), PA(*vs), FA(*ss), FA(*bc2), beta1, beta2, eps
 
     def zero_grad(self, set_to_none: bool = True) -> None:
+        # (directly: torch.optim.Optimizer.zero_grad costs ~20 us of host time per optimizer --
+        # profiler scopes, dynamo wrappers -- i.e. 0.1 ms per step for the six of them, a fifth of
+        # the step's host time; with the optimizer in the backward the gradients are None anyway)
         for opt in self.optimizers.values():
-            opt.zero_grad(set_to_none=set_to_none)
+            for grp in opt.param_groups:
+                for p in grp["params"]:
+                    if p.grad is None:
+                        continue
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.detach_()
+                        p.grad.requires_grad_(False)
+                        p.grad.zero_()
 
     def values(self):
         """Iterating `.values()` and calling step()/zero_grad() on each (the

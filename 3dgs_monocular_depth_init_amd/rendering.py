@@ -23,6 +23,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from ._lib import current_stream as _raw_stream
 from ._lib import call, ptr
 
 TILE = 16
@@ -33,7 +34,7 @@ GR_MEAN2D, GR_CONIC, GR_OPAC, GR_COLOR, GR_ABS = 0, 2, 5, 6, 12
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 class GradArena:
