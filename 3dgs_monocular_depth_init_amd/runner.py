@@ -157,7 +157,7 @@ def train_step(
         splats, camtoworlds, Ks, width, height, cfg,
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         render_mode="RGB")
-    colors = renders[..., :3]
+    colors = renders if renders.shape[-1] == 3 else renders[..., :3]     # (no slice node in the RGB case)
     if strategy is not None:
         strategy.step_pre_backward(splats, optimizers, strategy_state, step, info)   # runner.py:497
     if ssim_lambda > 0.0:
