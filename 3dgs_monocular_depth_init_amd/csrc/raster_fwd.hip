@@ -16,6 +16,22 @@
 
 namespace gsr {
 
+#ifdef GSR_FWD_TIMELINE
+// Diagnostic build only (tools/fwd_timeline.py): per tile, cycles spent in the segments of a
+// batch, summed over the tile's batches: [0] waiting for the gathered records, [1] building
+// the LDS image (make_rec, ds_write, barrier), [2] issuing the next batch's loads, [3] the
+// compositing loop, [4] whole kernel, [5] batches, [6] list length. s_memtime stamps, as
+// cdna_hip_programming.md section 7 prescribes (one asm statement with its lgkmcnt(0),
+// sched barriers around it); the values leave through a buffer nothing else reads.
+__device__ unsigned long long *g_fwd_timeline = nullptr;
+#define GSR_STAMP(t)                                                        \
+  do {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+  } while (0)
+#endif
+
 template <int CH>
 __global__ void __launch_bounds__(64, (CH <= 3) ? 8 : 5)
 raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
@@ -79,6 +95,11 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   int id_next = (e > s) ? flatten_ids[min(s + 64 + lane, e - 1)] : 0;
   constexpr int buf = 0;
   unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
+#ifdef GSR_FWD_TIMELINE
+  unsigned long long tl_t0, tl_a, tl_b, tl_c, tl_d, tl_e;
+  unsigned long long tl_wait = 0, tl_rec = 0, tl_issue = 0, tl_loop = 0, tl_batches = 0;
+  GSR_STAMP(tl_t0);
+#endif
   for (int base = s; base < e; base += 64) {
     // drop quadrants whose 64 pixels are all finished (or outside the image)
 #pragma unroll
@@ -87,6 +108,11 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     if (live == 0) break;
     const int n = min(64, e - base);
     bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp
+#ifdef GSR_FWD_TIMELINE
+    GSR_STAMP(tl_a);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSR_STAMP(tl_b);
+#endif
     if (lane < n) {
       make_rec<CH>(raw, ftx0, fty0, rec);
       can_clamp = rec.b.y > gs::ALPHA_MAX;
@@ -95,8 +121,14 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
       sRec[buf][2][lane] = rec.c;
     }
     __syncthreads();
+#ifdef GSR_FWD_TIMELINE
+    GSR_STAMP(tl_c);
+#endif
     load_raw<CH>(id_next, records, raw);
     id_next = flatten_ids[min(base + 128 + lane, e - 1)];
+#ifdef GSR_FWD_TIMELINE
+    GSR_STAMP(tl_d);
+#endif
 
     // One Gaussian against the tile. NOCLAMP (wave-uniform per batch): no opacity of the
     // batch exceeds 0.999, so min(0.999, .) is compiled out.
@@ -149,7 +181,23 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     } else {
       for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
     }
+#ifdef GSR_FWD_TIMELINE
+    GSR_STAMP(tl_e);
+    tl_wait += tl_b - tl_a;
+    tl_rec += tl_c - tl_b;
+    tl_issue += tl_d - tl_c;
+    tl_loop += tl_e - tl_d;
+    tl_batches += 1;
+#endif
   }
+#ifdef GSR_FWD_TIMELINE
+  GSR_STAMP(tl_e);
+  if (g_fwd_timeline && lane == 0) {
+    unsigned long long *o = g_fwd_timeline + 8 * (size_t)blockIdx.x;
+    o[0] = tl_wait; o[1] = tl_rec; o[2] = tl_issue; o[3] = tl_loop;
+    o[4] = tl_e - tl_t0; o[5] = tl_batches; o[6] = (unsigned long long)(e - s); o[7] = tl_t0;
+  }
+#endif
 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -202,6 +250,14 @@ pack_records_kernel(int64_t total, int N, int CH, const float *__restrict__ mean
 }
 
 }  // namespace gsr
+
+#ifdef GSR_FWD_TIMELINE
+extern "C" int gsr_debug_set_fwd_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_fwd_timeline), &p, sizeof(p)));
+  return GSR_OK;
+}
+#endif
 
 extern "C" int gsr_pack_records(int C, int N, int CH, const float *means2d, const float *conics,
                                 const float *colors, int color_stride, const float *opacities,
