@@ -14,6 +14,6 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace gsr
 
-extern "C" int gsr_version(void) { return 1; }
+extern "C" int gsr_version(void) { return 2; }   // 2: pair words + tight lists (round 3)
 extern "C" const char *gsr_last_error(void) { return gsr::g_err; }
 extern "C" const char *gsr_arch(void) { return "gfx950"; }

@@ -9,10 +9,21 @@
 // camera): every 1024-thread workgroup histograms its slice of the Gaussians in
 // LDS and touches global memory with one atomic per non-empty bucket (~1e5 per
 // frame); each bucket is then sorted INSIDE LDS by the composite key
-//   [63:61] tile-in-bucket | [60:30] depth bits (sign dropped) | [29:0] g
+//   [63:61] tile-in-bucket | [60:30] depth bits (sign dropped) | [29:4] g | [3:0] quadrant mask
 // which yields, in one pass, the per-tile start offsets and the depth-sorted
-// (ties by g) lists -- the same order as isect.hip / a stable global sort.
-#include "common.h"
+// (ties by g) lists -- the same order as isect.hip / a stable global sort (the mask is a
+// function of (tile, g), so it never decides a comparison).
+//
+// Round 3: the pair's quadrant mask (raster_common.h) is computed HERE, once (in the emit pass,
+// under the latency of its scatter), and handed to the compositing kernels in the pair words; with
+// `tight` lists a pair whose ellipse (alpha >= 1/255) misses all four quadrants of the tile is not
+// listed -- gsplat's bounding-rectangle rule lists it, and 17.5 % of the c4 pairs are of that kind
+// (profiles/r03_pair_stats.jsonl). The count pass keeps the rectangle rule (integer arithmetic;
+// evaluating the exact test there as well cost 30 us): its counts size the bucket regions, the emit
+// pass fills what it does not use with sentinels, and the sort pass compacts. Tight lists render the same image and gradients (the
+// dropped pairs contribute alpha < 1/255 everywhere, which both rules discard); the default
+// keeps gsplat's lists bit for bit.
+#include "raster_common.h"
 
 namespace gsr {
 
@@ -21,9 +32,27 @@ constexpr int BK_MAX_BUCKETS = 8192;     // LDS: 2 x 4 B x buckets = 64 KB
 constexpr int BK_SORT_CAP = 8192;        // entries sorted in LDS per bucket (64 KB)
 constexpr int BK_THREADS = 1024;
 
-__device__ __forceinline__ uint64_t bk_key(int tloc, float depth, uint32_t g) {
+constexpr int BK_G_BITS = 26;            // g = camera * N + Gaussian < 2^26 in the composite key
+__device__ __forceinline__ uint64_t bk_key(int tloc, float depth, uint32_t g, int mask) {
   return ((uint64_t)tloc << 61) | ((uint64_t)(__float_as_uint(depth) & 0x7fffffffu) << 30) |
-         (uint64_t)(g & 0x3fffffffu);
+         ((uint64_t)(g & 0x3ffffffu) << 4) | (uint64_t)(mask & 15);
+}
+__device__ __forceinline__ uint32_t bk_key_g(uint64_t k) { return (uint32_t)(k >> 4) & 0x3ffffffu; }
+__device__ __forceinline__ uint32_t bk_key_pair(uint64_t k) {
+  return bk_key_g(k) | ((uint32_t)(k & 15) << PAIR_MASK_SHIFT);
+}
+
+// What the exact pair test needs of a projected Gaussian.
+typedef PairConic PairGauss;
+__device__ __forceinline__ PairGauss load_pair_gauss(const float *__restrict__ means2d,
+                                                     const float *__restrict__ conics,
+                                                     const float *__restrict__ opacities,
+                                                     int opac_per_camera, int64_t g, int N, int C) {
+  return make_pair_conic(means2d[g * 2], means2d[g * 2 + 1], conics[g * 3], conics[g * 3 + 1],
+                         conics[g * 3 + 2], opacities[(opac_per_camera || C == 1) ? g : (g % N)]);
+}
+__device__ __forceinline__ int pair_mask_of(const PairGauss &p, int tx, int ty) {
+  return pair_quadrant_mask(p, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE));
 }
 
 // Walk the buckets a Gaussian's tile rectangle touches: f(bucket, first tile x, last tile x + 1, y)
@@ -37,13 +66,22 @@ __device__ __forceinline__ void for_each_bucket(int c, int x0, int x1, int y0, i
   }
 }
 
-// Pass 1: entries per bucket. Each workgroup owns a contiguous slice of the pairs.
+// Pass 1: entries per bucket under gsplat's rule (bounding rectangle x tile grid: integer
+// arithmetic only). For tight lists this is an UPPER bound that sizes the bucket regions; the emit
+// pass, which evaluates the exact pair test anyway, leaves the surplus slots as sentinels.
+// Also clears the two per-frame counters the emit pass uses (nothing reads them before it).
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
-                    const int32_t *__restrict__ radii, int tile_w, int tile_h, int bw,
-                    int n_buckets, int64_t chunk, int32_t *__restrict__ bucket_counts) {
+                    const int32_t *__restrict__ radii, int tile_w, int tile_h, int bw, int n_buckets,
+                    int64_t chunk, int32_t *__restrict__ bucket_counts,
+                    int32_t *__restrict__ clear_a, int32_t *__restrict__ clear_b) {
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) hist[b] = 0;
+  if (clear_a)
+    for (int b = blockIdx.x * BK_THREADS + threadIdx.x; b < n_buckets; b += gridDim.x * BK_THREADS) {
+      clear_a[b] = 0;
+      clear_b[b] = 0;
+    }
   __syncthreads();
   const int64_t total = (int64_t)C * N;
   const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
@@ -58,43 +96,156 @@ bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
     if (hist[b] > 0) atomicAdd(&bucket_counts[b], hist[b]);
 }
 
-// Pass 2: scatter the composite keys into their buckets (unordered inside a bucket).
+// Exclusive scan of a[0..n) in LDS by the whole workgroup (n <= 8192); returns the total.
+// Every thread owns 8 consecutive elements.
+__device__ __forceinline__ int bk_block_exclusive_scan(int32_t *a, int n, int32_t *wave_tot /* [17] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int v[8], local = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid * 8 + k;
+    v[k] = i < n ? a[i] : 0;
+    local += v[k];
+  }
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int prefix = 0, tot = 0;
+  for (int w = 0; w < BK_THREADS / 64; ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) prefix += t;
+    tot += t;
+  }
+  int run = prefix + incl - local;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = tid * 8 + k;
+    if (i < n) a[i] = run;
+    run += v[k];
+  }
+  __syncthreads();
+  return tot;
+}
+
+constexpr uint64_t BK_SENTINEL = ~0ull;   // a reserved slot no pair was written to (sorts last, skipped)
+constexpr int BK_ORDER_CLASSES = 64;
+
+// Pass 2: scatter the composite keys into their buckets (unordered inside a bucket). Every
+// workgroup scans the bucket counts itself (no scan launch in between; workgroup 0 publishes the
+// offsets, the bucket work order and the total for the sort pass and the host). The exact pair test
+// runs here, once per pair, under the scatter's own latency; tight lists drop the pairs whose mask
+// is 0 and fill the slots reserved for them with sentinels. real_counts[b] = pairs actually listed.
+template <bool TIGHT>
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
                    const int32_t *__restrict__ radii, const float *__restrict__ depths,
-                   int tile_w, int tile_h, int bw, int n_buckets, int64_t chunk,
-                   const int32_t *__restrict__ bucket_offsets, int32_t *__restrict__ bucket_cursor,
-                   uint64_t *__restrict__ keys, int64_t capacity) {
+                   const float *__restrict__ conics, const float *__restrict__ opacities,
+                   int opac_per_camera, int tile_w, int tile_h, int bw, int n_buckets, int64_t chunk,
+                   const int32_t *__restrict__ bucket_counts, int32_t *__restrict__ bucket_cursor,
+                   int32_t *__restrict__ real_counts, int32_t *__restrict__ bucket_offsets,
+                   int32_t *__restrict__ bucket_order, int32_t *__restrict__ tile_order,
+                   int32_t *__restrict__ total_host, uint64_t *__restrict__ keys, int64_t capacity) {
   extern __shared__ int32_t lds[];
-  int32_t *hist = lds, *base = lds + n_buckets;
-  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) hist[b] = 0;
+  int32_t *hist = lds, *base = lds + n_buckets, *resv = lds + 2 * n_buckets;
+  __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
+  __shared__ int32_t cls[BK_ORDER_CLASSES], clt[BK_ORDER_CLASSES];
+  const int tid = threadIdx.x;
+  for (int b = tid; b < n_buckets; b += BK_THREADS) {
+    hist[b] = 0;
+    base[b] = bucket_counts[b];
+  }
   __syncthreads();
+  if (blockIdx.x == 0 && (bucket_order || tile_order)) {
+    // work orders, longest first, in 64 length classes of the rectangle-rule counts: of the buckets
+    // for the sort pass, and of the TILES for the compositing kernels (bucket by bucket: the 8 tiles
+    // of a bucket are neighbours with lists of similar length; a tile-exact order needed a launch
+    // of its own after the sort pass, 8 us on one workgroup)
+    auto cl = [&](int len) { return BK_ORDER_CLASSES - 1 - min(BK_ORDER_CLASSES - 1, (len + 127) >> 7); };
+    auto ntile = [&](int b) { return min(BK_TILES, tile_w - (b % bw) * BK_TILES); };   // tiles of bucket b
+    if (tid < BK_ORDER_CLASSES) cls[tid] = clt[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < n_buckets; b += BK_THREADS) {
+      atomicAdd(&cls[cl(base[b])], 1);
+      atomicAdd(&clt[cl(base[b])], ntile(b));
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0, runt = 0;
+      for (int k = 0; k < BK_ORDER_CLASSES; ++k) {
+        const int c = cls[k], t = clt[k];
+        cls[k] = run;
+        clt[k] = runt;
+        run += c;
+        runt += t;
+      }
+    }
+    __syncthreads();
+    for (int b = tid; b < n_buckets; b += BK_THREADS) {
+      const int k = cl(base[b]);
+      if (bucket_order) bucket_order[atomicAdd(&cls[k], 1)] = b;
+      if (tile_order) {
+        const int nt = ntile(b), at = atomicAdd(&clt[k], nt);
+        const int first = (b / bw) * tile_w + (b % bw) * BK_TILES;   // row = cam*tile_h + ty
+        for (int j = 0; j < nt; ++j) tile_order[at + j] = first + j;
+      }
+    }
+    __syncthreads();
+  }
+  const int total_slots = bk_block_exclusive_scan(base, n_buckets, wave_tot);   // base = bucket offsets
+  if (blockIdx.x == 0) {
+    for (int b = tid; b < n_buckets; b += BK_THREADS) bucket_offsets[b] = base[b];
+    if (tid == 0) {
+      bucket_offsets[n_buckets] = total_slots;
+      // the host's copy, stored straight into pinned host memory; visible once an event recorded
+      // after this kernel has completed
+      if (total_host) __hip_atomic_store(total_host, total_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   const int64_t total = (int64_t)C * N;
   const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
-  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
+  for (int64_t g = g0 + tid; g < g1; g += BK_THREADS) {
     int x0, x1, y0, y1;
     if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h,
+    for_each_bucket(C == 1 ? 0 : (int)(g / N), x0, x1, y0, y1, bw, tile_h,
                     [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
   }
   __syncthreads();
   // reserve this workgroup's range in every bucket it feeds (one atomic per bucket)
-  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) {
+  for (int b = tid; b < n_buckets; b += BK_THREADS) {
     const int h = hist[b];
-    base[b] = (h > 0) ? bucket_offsets[b] + atomicAdd(&bucket_cursor[b], h) : 0;
+    resv[b] = h;
+    base[b] = (h > 0) ? base[b] + atomicAdd(&bucket_cursor[b], h) : 0;
     hist[b] = 0;   // becomes the local cursor
   }
   __syncthreads();
-  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
+  for (int64_t g = g0 + tid; g < g1; g += BK_THREADS) {
     int x0, x1, y0, y1;
     if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
+    const int c = C == 1 ? 0 : (int)(g / N);
     const float d = depths[g];
-    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h, [&](int b, int xa, int xb, int) {
-      const int n = xb - xa;
-      const int64_t p = (int64_t)base[b] + atomicAdd(&hist[b], n);
-      for (int k = 0; k < n; ++k)
-        if (p + k < capacity) keys[p + k] = bk_key((xa + k) & (BK_TILES - 1), d, (uint32_t)g);
-    });
+    const PairGauss p = load_pair_gauss(means2d, conics, opacities, opac_per_camera, g, N, C);
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const int m = pair_mask_of(p, x, y);
+        if (TIGHT && m == 0) continue;
+        const int b = (c * tile_h + y) * bw + x / BK_TILES;
+        const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
+        if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), d, (uint32_t)g, m);
+      }
+  }
+  __syncthreads();
+  for (int b = tid; b < n_buckets; b += BK_THREADS) {
+    const int h = resv[b], r = hist[b];
+    if (h == 0) continue;
+    if (TIGHT)
+      for (int k = r; k < h; ++k)
+        if ((int64_t)base[b] + k < capacity) keys[(int64_t)base[b] + k] = BK_SENTINEL;
+    if (r > 0) atomicAdd(&real_counts[b], r);
   }
 }
 
@@ -213,74 +364,94 @@ tile_order_kernel(int n, const int32_t *__restrict__ tile_offsets, int32_t *__re
   tile_order_body(n, tile_offsets, tile_order, threadIdx.x, 1024);
 }
 
-// Pass 3: one workgroup per bucket. The keys are split by tile-in-bucket while they are
-// loaded into LDS (8-bin counting sort), then the 8 tile segments are depth-sorted side
-// by side, each by its own 128-thread group; flatten_ids and the tile offsets follow.
+// Pass 3: one workgroup per bucket. The bucket's region holds its listed pairs (and, for tight
+// lists, sentinels in the slots the rectangle rule reserved for dropped pairs). The real keys are
+// split by tile-in-bucket while they are loaded into LDS (8-bin counting sort), then the 8 tile
+// segments are depth-sorted side by side, each by its own 128-thread group; the lists are written
+// COMPACTED: the bucket's output position is the sum of the real counts of the buckets before it.
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
-                   const int32_t *__restrict__ bucket_order, uint64_t *__restrict__ keys,
-                   int32_t *__restrict__ flatten_ids, int32_t *__restrict__ tile_offsets,
-                   int n_tiles, int capacity, int32_t *__restrict__ clear_counts) {
+                   const int32_t *__restrict__ bucket_order, const int32_t *__restrict__ real_counts,
+                   uint64_t *__restrict__ keys, uint64_t *__restrict__ keys_sorted,
+                   int32_t *__restrict__ flatten_ids, int32_t *__restrict__ pair_ids,
+                   int32_t *__restrict__ tile_offsets, int n_tiles, int capacity,
+                   int32_t *__restrict__ clear_counts, int32_t *__restrict__ total_host) {
   __shared__ uint64_t sk[BK_SORT_CAP];
   __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], seg_cur[BK_TILES], npad_max_s;
+  __shared__ int32_t red[BK_THREADS / 64], out_base_s;
   const int tid = threadIdx.x;
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
   // `capacity` = entries the key / id buffers hold. The caller may size them from the
   // previous frame without waiting for this frame's total: everything is clamped so an
   // overflowing frame yields truncated (then discarded) lists, never an out-of-bounds access.
   const int s = min(bucket_offsets[b], capacity), e = min(bucket_offsets[b + 1], capacity);
-  const int L = e - s;
+  const int LA = e - s;                               // slots of the region (real keys + sentinels)
   const int row = b / bw, bx = b - row * bw;          // row = cam*tile_h + ty
-  if (L <= BK_SORT_CAP) {
+  // output position of this bucket: real pairs of all buckets before it
+  {
+    int acc = 0;
+    for (int i = tid; i < b; i += BK_THREADS) acc += real_counts[i];
+    acc = wave_sum_i32(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
     if (tid < BK_TILES) seg_cnt[tid] = 0;
     __syncthreads();
-    for (int t = tid; t < L; t += BK_THREADS) atomicAdd(&seg_cnt[(int)(keys[s + t] >> 61)], 1);
-    __syncthreads();
     if (tid == 0) {
-      int run = 0, mx = 0;
-      for (int q = 0; q < BK_TILES; ++q) {
-        seg_start[q] = run;
-        seg_cur[q] = run;
-        run += seg_cnt[q];
-        mx = max(mx, seg_cnt[q]);
-      }
-      seg_start[BK_TILES] = run;
-      int np = 1;
-      while (np < mx) np <<= 1;
-      npad_max_s = np;
+      int t = 0;
+      for (int w = 0; w < BK_THREADS / 64; ++w) t += red[w];
+      out_base_s = t;
     }
-    __syncthreads();
-    for (int t = tid; t < L; t += BK_THREADS) {
+  }
+  for (int t = tid; t < LA; t += BK_THREADS) {
+    const uint64_t k = keys[s + t];
+    if (k != BK_SENTINEL) atomicAdd(&seg_cnt[(int)(k >> 61)], 1);
+  }
+  __syncthreads();
+  const int out_base = out_base_s;
+  if (tid == 0) {
+    int run = 0, mx = 0;
+    for (int q = 0; q < BK_TILES; ++q) {
+      seg_start[q] = run;
+      seg_cur[q] = run;
+      run += seg_cnt[q];
+      mx = max(mx, seg_cnt[q]);
+    }
+    seg_start[BK_TILES] = run;
+    int np = 1;
+    while (np < mx) np <<= 1;
+    npad_max_s = np;
+  }
+  __syncthreads();
+  const int L = seg_start[BK_TILES];                  // real pairs of this bucket
+  auto put = [&](int t, uint64_t k) {
+    const int64_t o = (int64_t)out_base + t;
+    if (o < capacity) {
+      flatten_ids[o] = (int32_t)bk_key_g(k);
+      pair_ids[o] = (int32_t)bk_key_pair(k);
+      if (keys_sorted) keys_sorted[o] = k;
+    }
+  };
+  if (L <= BK_SORT_CAP) {
+    for (int t = tid; t < LA; t += BK_THREADS) {
       const uint64_t k = keys[s + t];
-      sk[atomicAdd(&seg_cur[(int)(k >> 61)], 1)] = k;
+      if (k != BK_SENTINEL) sk[atomicAdd(&seg_cur[(int)(k >> 61)], 1)] = k;
     }
     __syncthreads();
     const int grp = tid >> 7;                          // 8 groups of 128 threads
     bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
-    for (int t = tid; t < L; t += BK_THREADS) {
-      const uint64_t k = sk[t];
-      keys[s + t] = k;
-      flatten_ids[s + t] = (int32_t)(k & 0x3fffffffu);
-    }
-    if (tid < BK_TILES && bx * BK_TILES + tid < tile_w)
-      tile_offsets[row * tile_w + bx * BK_TILES + tid] = s + seg_start[tid];
-  } else {   // longer than the LDS sorter: one composite-key network in global memory (slow, exact)
-    bk_bitonic<false>(keys + s, L, tid);
-    for (int t = tid; t < L; t += BK_THREADS)
-      flatten_ids[s + t] = (int32_t)(keys[s + t] & 0x3fffffffu);
-    __syncthreads();
-    // start offset of each tile = first entry whose tile-in-bucket >= t
-    if (tid < BK_TILES && bx * BK_TILES + tid < tile_w) {
-      int lo = 0, hi = L;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((int)(keys[s + mid] >> 61) < tid) lo = mid + 1; else hi = mid;
-      }
-      tile_offsets[row * tile_w + bx * BK_TILES + tid] = s + lo;
-    }
+    for (int t = tid; t < L; t += BK_THREADS) put(t, sk[t]);
+  } else {   // longer than the LDS sorter: one composite-key network in global memory (slow, exact);
+             // sentinels are the largest key and end up behind the L real ones
+    bk_bitonic<false>(keys + s, LA, tid);
+    for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);
   }
-  if (b == n_buckets - 1 && tid == 0) tile_offsets[n_tiles] = e;
-  if (clear_counts && tid == 0) clear_counts[b] = 0;   // the emit cursor of this bucket: zero for the next frame
+  if (tid < BK_TILES && bx * BK_TILES + tid < tile_w)
+    tile_offsets[row * tile_w + bx * BK_TILES + tid] = min(out_base + seg_start[tid], capacity);
+  if (b == n_buckets - 1 && tid == 0) {
+    tile_offsets[n_tiles] = min(out_base + L, capacity);
+    if (total_host)
+      __hip_atomic_store(total_host, out_base + L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (clear_counts && tid == 0) clear_counts[b] = 0;   // the count of this bucket: zero for the next frame
 }
 
 // tile_order (longest list first) from finished tile offsets; one workgroup.
@@ -302,58 +473,79 @@ extern "C" int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int
 }
 
 extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii,
-                                int tile_w, int tile_h, int32_t *bucket_counts, int assume_zero,
-                                void *stream) {
+                                int tile_w, int tile_h, int32_t *bucket_counts, int32_t *clear_a,
+                                int32_t *clear_b, int assume_zero, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && bucket_counts, "bucket_count: bad arguments");
+  GSR_REQUIRE((clear_a == nullptr) == (clear_b == nullptr), "bucket_count: clear_a and clear_b go together");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
     gsr::set_error("bucket_count: %d buckets exceed the LDS histogram (%d)", nb, gsr::BK_MAX_BUCKETS);
     return GSR_ECAPACITY;
   }
-  GSR_REQUIRE((int64_t)C * N < (1LL << 30), "bucket_count: C*N must be < 2^30 (composite key)");
+  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_count: C*N must be < 2^26 (composite key)");
   if (nb > 0 && !assume_zero)
     GSR_CHECK_HIP(hipMemsetAsync(bucket_counts, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
   const int64_t total = (int64_t)C * N;
-  if (total == 0 || nb == 0) return GSR_OK;
+  if (nb == 0) return GSR_OK;
+  if (total == 0) {
+    if (clear_a) {
+      GSR_CHECK_HIP(hipMemsetAsync(clear_a, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+      GSR_CHECK_HIP(hipMemsetAsync(clear_b, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+    }
+    return GSR_OK;
+  }
   GSR_REQUIRE(means2d && radii, "bucket_count: null pointer");
   int64_t chunk;
   const int grid = gsr::bk_grid(total, &chunk);
   hipLaunchKernelGGL(gsr::bucket_count_kernel, dim3(grid), dim3(gsr::BK_THREADS),
                      sizeof(int32_t) * nb, (hipStream_t)stream, C, N, means2d, radii, tile_w, tile_h,
-                     bw, nb, chunk, bucket_counts);
+                     bw, nb, chunk, bucket_counts, clear_a, clear_b);
   GSR_CHECK_LAUNCH("bucket_count");
   return GSR_OK;
 }
 
 extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii,
-                               const float *depths, int tile_w, int tile_h,
-                               const int32_t *bucket_offsets, int32_t *bucket_cursor,
-                               uint64_t *keys, int64_t capacity, int assume_zero, void *stream) {
+                               const float *depths, const float *conics, const float *opacities,
+                               int opac_per_camera, int tile_w, int tile_h, int tight,
+                               const int32_t *bucket_counts, int32_t *bucket_cursor,
+                               int32_t *real_counts, int32_t *bucket_offsets, int32_t *bucket_order,
+                               int32_t *tile_order, int32_t *total_host, uint64_t *keys,
+                               int64_t capacity, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && capacity >= 0, "bucket_emit: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
     gsr::set_error("bucket_emit: %d buckets exceed the LDS histogram", nb);
     return GSR_ECAPACITY;
   }
+  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_emit: C*N must be < 2^26 (composite key)");
   const int64_t total = (int64_t)C * N;
-  if (total == 0 || nb == 0) return GSR_OK;
-  GSR_REQUIRE(means2d && radii && depths && bucket_offsets && bucket_cursor && (keys || capacity == 0),
+  if (nb == 0) return GSR_OK;
+  GSR_REQUIRE(bucket_counts && bucket_cursor && real_counts && bucket_offsets && (keys || capacity == 0),
               "bucket_emit: null pointer");
-  if (!assume_zero)
-    GSR_CHECK_HIP(hipMemsetAsync(bucket_cursor, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
+  GSR_REQUIRE(total == 0 || (means2d && radii && depths && conics && opacities), "bucket_emit: null pointer");
   int64_t chunk;
-  const int grid = gsr::bk_grid(total, &chunk);
-  hipLaunchKernelGGL(gsr::bucket_emit_kernel, dim3(grid), dim3(gsr::BK_THREADS),
-                     2 * sizeof(int32_t) * nb, (hipStream_t)stream, C, N, means2d, radii, depths,
-                     tile_w, tile_h, bw, nb, chunk, bucket_offsets, bucket_cursor, keys, capacity);
+  const int grid = gsr::bk_grid(total, &chunk);   // >= 1 workgroup even for an empty scene: it publishes the offsets
+  const size_t lds = 3 * sizeof(int32_t) * nb;
+  if (tight)
+    hipLaunchKernelGGL(gsr::bucket_emit_kernel<true>, dim3(grid), dim3(gsr::BK_THREADS), lds,
+                       (hipStream_t)stream, C, N, means2d, radii, depths, conics, opacities,
+                       opac_per_camera, tile_w, tile_h, bw, nb, chunk, bucket_counts, bucket_cursor,
+                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity);
+  else
+    hipLaunchKernelGGL(gsr::bucket_emit_kernel<false>, dim3(grid), dim3(gsr::BK_THREADS), lds,
+                       (hipStream_t)stream, C, N, means2d, radii, depths, conics, opacities,
+                       opac_per_camera, tile_w, tile_h, bw, nb, chunk, bucket_counts, bucket_cursor,
+                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity);
   GSR_CHECK_LAUNCH("bucket_emit");
   return GSR_OK;
 }
 
 extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
-                               const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
-                               int32_t *tile_offsets, int32_t *tile_order, int64_t capacity,
-                               int32_t *clear_counts, void *stream) {
+                               const int32_t *bucket_order, const int32_t *real_counts,
+                               uint64_t *keys, uint64_t *keys_sorted, int32_t *flatten_ids,
+                               int32_t *pair_ids, int32_t *tile_offsets, int32_t *tile_order,
+                               int64_t capacity, int32_t *clear_counts, int32_t *total_host,
+                               void *stream) {
   GSR_REQUIRE(C >= 0 && tile_w > 0 && tile_h > 0, "bucket_sort: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -361,17 +553,56 @@ extern "C" int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *buc
     return GSR_ECAPACITY;
   }
   if (nb == 0) return GSR_OK;
-  GSR_REQUIRE(bucket_offsets && tile_offsets && capacity >= 0, "bucket_sort: bad arguments");
+  GSR_REQUIRE(bucket_offsets && real_counts && tile_offsets && capacity >= 0 &&
+                  ((flatten_ids && pair_ids && keys) || capacity == 0),
+              "bucket_sort: bad arguments");
   const int n_tiles = C * tile_w * tile_h;
   hipLaunchKernelGGL(gsr::bucket_sort_kernel, dim3(nb), dim3(gsr::BK_THREADS), 0,
-                     (hipStream_t)stream, nb, tile_w, bw, bucket_offsets, bucket_order, keys,
-                     flatten_ids, tile_offsets, n_tiles,
-                     (int)(capacity < 2147483647LL ? capacity : 2147483647LL), clear_counts);
+                     (hipStream_t)stream, nb, tile_w, bw, bucket_offsets, bucket_order, real_counts, keys,
+                     keys_sorted, flatten_ids, pair_ids, tile_offsets, n_tiles,
+                     (int)(capacity < 2147483647LL ? capacity : 2147483647LL), clear_counts, total_host);
   GSR_CHECK_LAUNCH("bucket_sort");
   if (tile_order) {
     hipLaunchKernelGGL(gsr::tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
                        tile_offsets, tile_order);
     GSR_CHECK_LAUNCH("tile_order");
   }
+  return GSR_OK;
+}
+
+namespace gsr {
+// Pair words for tile lists built elsewhere (isect.hip, a caller's own lists): one workgroup
+// per tile evaluates the quadrant masks of its entries.
+__global__ void __launch_bounds__(256)
+pair_masks_kernel(int C, int N, int tile_w, int tile_h, const int32_t *__restrict__ tile_offsets,
+                  const int32_t *__restrict__ flatten_ids, const float *__restrict__ means2d,
+                  const float *__restrict__ conics, const float *__restrict__ opacities,
+                  int opac_per_camera, int32_t *__restrict__ pair_ids) {
+  const int tile = blockIdx.x;
+  const int tin = tile % (tile_w * tile_h);
+  const int ty = tin / tile_w, tx = tin - ty * tile_w;
+  const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
+  for (int i = s + (int)threadIdx.x; i < e; i += 256) {
+    const uint32_t g = (uint32_t)flatten_ids[i];
+    const PairGauss p = load_pair_gauss(means2d, conics, opacities, opac_per_camera, (int64_t)g, N, C);
+    pair_ids[i] = (int32_t)(g | ((uint32_t)pair_mask_of(p, tx, ty) << PAIR_MASK_SHIFT));
+  }
+}
+}  // namespace gsr
+
+extern "C" int gsr_pair_masks(int C, int N, int tile_w, int tile_h, const int32_t *tile_offsets,
+                              const int32_t *flatten_ids, const float *means2d, const float *conics,
+                              const float *opacities, int opac_per_camera, int32_t *pair_ids,
+                              void *stream) {
+  GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0, "pair_masks: bad sizes");
+  GSR_REQUIRE((int64_t)C * N <= (int64_t)gsr::PAIR_ID_MASK, "pair_masks: C*N must be < 2^28 (pair word)");
+  const int n_tiles = C * tile_w * tile_h;
+  if (n_tiles == 0 || (int64_t)C * N == 0) return GSR_OK;
+  GSR_REQUIRE(tile_offsets && flatten_ids && means2d && conics && opacities && pair_ids,
+              "pair_masks: null pointer");
+  hipLaunchKernelGGL(gsr::pair_masks_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, C, N,
+                     tile_w, tile_h, tile_offsets, flatten_ids, means2d, conics, opacities,
+                     opac_per_camera, pair_ids);
+  GSR_CHECK_LAUNCH("pair_masks");
   return GSR_OK;
 }

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "adam_math.h"
 #include "gs_math.h"
+#include "raster_common.h"
 
 namespace gsr {
 
@@ -164,10 +165,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     float cc5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < color_stride && k < 5; ++k) cc5[k] = co[k];
     const float op_eff = calc_comp ? opac * p.comp : opac;
-    float4 *row = reinterpret_cast<float4 *>(records + g * 16);
-    row[0] = make_float4(p.mx, p.my, p.ca, p.cb);
-    row[1] = make_float4(p.cc, op_eff, cc5[0], cc5[1]);
-    row[2] = make_float4(cc5[2], cc5[3], cc5[4], 0.f);
+    write_record(records, g, p.mx, p.my, p.ca, p.cb, p.cc, op_eff, cc5);
   }
 }
 

@@ -3,14 +3,22 @@
 // Replaces gsplat's rasterize_to_pixels backward that loss.backward()
 // (gs_init_compare/runner.py:547) triggers. Same shape as the forward: one
 // wave64 per 16x16 tile, 2x2 pixels per lane, tile list replayed back to front
-// in LDS batches of 64. Per Gaussian the lane sums its 4 pixels in registers,
-// the wave reduces on DPP (no LDS), and the batch's totals are parked in LDS
-// as [64][16] rows; each row is then flushed with ONE 64-byte-aligned group
-// of float atomics into grad_rows[g][16] (16 adjacent lanes = one memory-side
-// atomic request), instead of 9-11 scattered dword atomics per Gaussian.
+// in LDS batches of 32 (records and pair words by LDS-DMA, one batch ahead; the
+// quadrant masks arrive with the pair words). Per Gaussian the lane sums its 4
+// pixels in registers, the wave reduces on DPP / lane swaps (no LDS), and the
+// batch's totals are parked in LDS as [32][16] rows; each row is then flushed with
+// ONE 64-byte-aligned group of float atomics into grad_rows[g][16] (16 adjacent
+// lanes = one memory-side atomic request), instead of 9-11 scattered dword
+// atomics per Gaussian. The flush of batch k runs at the top of batch k+1, BEFORE
+// the DMA of batch k+2 is issued: the batch-top wait (vmcnt(0), the DMA has no other
+// completion signal) then only ever waits for atomics that are a whole batch old.
 #include <type_traits>
 
 #include "raster_common.h"
+
+#ifndef GSR_BWD_WAVES
+#define GSR_BWD_WAVES 6   // waves per SIMD the CH <= 3 instantiation is register-allocated for
+#endif
 
 namespace gsr {
 
@@ -24,21 +32,20 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 template <int CH, bool ABSGRAD>
-__global__ void __launch_bounds__(64, (CH <= 3 && !ABSGRAD) ? 5 : 4)
+__global__ void __launch_bounds__(64, (CH <= 3 && !ABSGRAD) ? GSR_BWD_WAVES : 4)
 raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ tile_order,
-                  const int32_t *__restrict__ flatten_ids,
+                  const int32_t *__restrict__ pair_ids,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
                   const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows) {
-  // staged batch: [0] = {mx, my, ha, bb}, [1] = {hc, opacity, col0, col1},
-  // [2] = {col2, col3, col4, quadrant mask}. One array, so that the three wave-uniform
-  // reads of a Gaussian share one address register (base + j*16, offsets 0/1024/2048).
-  __shared__ float4 sRec[3][64];
-  __shared__ int sId[1][64];
-  __shared__ __attribute__((aligned(16))) float sG[64][GSR_GRAD_ROW];  // batch gradient rows
+  // staged batches: row r = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | -}
+  // of the batch's r-th Gaussian (r = 0 is the LAST list position of the batch)
+  __shared__ __attribute__((aligned(16))) float4 sRec[2][RBATCH][4];
+  __shared__ uint32_t sPw[PW_SLOTS][RBATCH];
+  __shared__ __attribute__((aligned(16))) float sG[RBATCH][GSR_GRAD_ROW];  // batch gradient rows
 
   if ((int)blockIdx.x >= n_tiles) return;
   const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
@@ -49,10 +56,6 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
-  // tile origin as floats held in SCALAR registers (wave-uniform; a VGPR copy would be
-  // hoisted out of the loops and cost the compositing loops registers)
-  const float ftx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)tx0)));
-  const float fty0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)ty0)));
 
   // Which field of a gradient row this lane stores after the reductions (-1: none):
   // lanes with (lane & 7) == 0 hold one tree_reduce8 total each -- tree values 0,1 = first
@@ -118,34 +121,53 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   // below it need neither the per-pixel "idx <= last" test nor the per-quadrant one
   const int min_last = -__builtin_amdgcn_readfirstlane(wave_max_i32(-my_min_last));
 
-  // lane l of a batch stages Gaussian (batch_end - l): j = 0 is the LAST one.
-  // Software pipeline: ids two batches ahead, record rows one batch ahead (in flight
-  // during the loop over the current batch), LDS image built after the loop.
-  RawRec<CH> raw;
-  TileRec<CH> rec;
-  // (loads are unconditional with clamped indices: a predicated load would merge old and
-  // new register values, and the copies that merge needs wait for the load right away)
-  int rId = flatten_ids[max(start - lane, s)];
-  load_raw<CH>(rId, records, raw);
-  int id_next = flatten_ids[max(start - 64 - lane, s)];
-
-  constexpr int buf = 0;
-  for (int batch_end = start; batch_end >= s; batch_end -= 64) {
-    const int n = min(64, batch_end - s + 1);
-    bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp (no gradient there)
-    if (lane < n) {
-      make_rec<CH>(raw, ftx0, fty0, rec);
-      can_clamp = rec.b.y > gs::ALPHA_MAX;
-      sRec[0][lane] = rec.a;
-      sRec[1][lane] = rec.b;
-      sRec[2][lane] = rec.c;
-      sId[buf][lane] = rId;
+  // Flush the parked rows of a finished batch: 4 Gaussians per wave instruction, 16 lanes = one
+  // 64-byte row. Reads the batch's records (conic for v_xy, opacity) and pair words (the ids).
+  auto flush = [&](int n, const float4(*rec)[4], const uint32_t *pw) {
+    const int f = lane & 15;
+    const bool field_used =
+        (f < GSR_GR_COLOR + CH) || (ABSGRAD && (f == GSR_GR_ABS || f == GSR_GR_ABS + 1));
+    for (int j0 = 0; j0 < n; j0 += 4) {
+      const int j = j0 + (lane >> 4);
+      if (j < n && field_used && sG[j][15] != 0.f) {
+        const uint32_t g = pw[j] & PAIR_ID_MASK;
+        float val = sG[j][f];
+        if (f < 2) {   // v_xy = conic * (first moments): row holds (m_x, m_y)
+          const float4 Aj = rec[j][0];
+          const float4 Bj = rec[j][1];
+          const float ca = Aj.z * (2.0f / LOG2E), cb = Aj.w * (1.0f / LOG2E),
+                      cc = Bj.x * (2.0f / LOG2E);
+          const float mx_ = sG[j][0], my_ = sG[j][1];
+          val = (f == 0) ? fmaf(ca, mx_, cb * my_) : fmaf(cb, mx_, cc * my_);
+        }
+        if (f == GSR_GR_OPAC) val = -val / rec[j][1].y;   // row holds sum v_sigma
+        if (f == GSR_GR_CONIC || f == GSR_GR_CONIC + 2) val *= 0.5f;
+        atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, val);
+      }
     }
-    sG[lane][15] = 0.f;   // "row touched" flag of Gaussian `lane` of this batch
-    __syncthreads();
-    rId = id_next;
-    load_raw<CH>(rId, records, raw);
-    id_next = flatten_ids[max(batch_end - 128 - lane, s)];
+  };
+
+  // batch k covers the list positions start - 32k - 31 .. start - 32k; its r-th Gaussian is
+  // position start - 32k - r. Pipeline: pair words two batches ahead, records one batch ahead.
+  dma_pair_words<-1>(pair_ids, start, s, start, lane, sPw[0]);
+  dma_pair_words<-1>(pair_ids, start - RBATCH, s, start, lane, sPw[1]);
+  GSR_WAIT_VMEM();
+  dma_stage_batch(records, sPw[0], lane, sRec[0]);
+  int buf = 0, slot = 0, n_prev = 0;
+  for (int batch_end = start; batch_end >= s; batch_end -= RBATCH, buf ^= 1, slot = (slot == 2) ? 0 : slot + 1) {
+    const int n = min(RBATCH, batch_end - s + 1);
+    GSR_WAIT_VMEM();   // this batch's records and the next batch's words are in LDS
+    const int s1 = (slot == 2) ? 0 : slot + 1, s2 = (s1 == 2) ? 0 : s1 + 1;   // s2 = previous batch's slot
+    if (n_prev > 0) flush(n_prev, sRec[buf ^ 1], sPw[s2]);
+    if (batch_end - RBATCH >= s) {
+      dma_stage_batch(records, sPw[s1], lane, sRec[buf ^ 1]);
+      dma_pair_words<-1>(pair_ids, batch_end - 2 * RBATCH, s, start, lane, sPw[s2]);
+    }
+    const float4(*rec)[4] = sRec[buf];
+    const uint32_t pw = sPw[slot][lane & 31];   // lane j < n: pair j's word (mask in the top bits)
+    // opacity > 0.999 somewhere in the batch: alpha may hit the clamp (no gradient there)
+    const bool can_clamp = (lane < n) && rec[lane & 31][1].y > gs::ALPHA_MAX;
+    if (lane < RBATCH) sG[lane][15] = 0.f;   // "row touched" flag of Gaussian `lane` of this batch
 
     // One Gaussian against the tile. FAST (wave-uniform, decided per batch): every pixel
     // is active and no opacity of the batch exceeds the alpha clamp, so the tests against
@@ -153,7 +175,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     const bool fast_batch = (batch_end <= min_last) && !__any(can_clamp);
     auto composite = [&](auto fast_tag, int j) {
       constexpr bool FAST = decltype(fast_tag)::value;
-      unsigned qm = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(sRec[2][j].w));
+      unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT;
       const int idx = batch_end - j;
       if (!FAST) {
 #pragma unroll
@@ -161,13 +183,13 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           if (idx > qmax[q]) qm &= ~(1u << q);   // scalar: no pixel of q blended this far down
       }
       if (qm == 0) return;
-      const float4 Ac = sRec[0][j], Bc = sRec[1][j];
+      const float4 Ac = rec[j][0], Bc = rec[j][1];
       float col[CH];
       col[0] = Bc.z;
       if (CH > 1) col[1] = Bc.w;
-      if (CH > 2) col[2] = sRec[2][j].x;
-      if (CH > 3) col[3] = sRec[2][j].y;
-      if (CH > 4) col[4] = sRec[2][j].z;
+      if (CH > 2) col[2] = rec[j][2].x;
+      if (CH > 3) col[3] = rec[j][2].y;
+      if (CH > 4) col[4] = rec[j][2].z;
       const float opac = Bc.y;
       // conic in natural units for the gradient formulas: a = 2*ha/log2e etc.
       const float ca = Ac.z * (2.0f / LOG2E), cb = Ac.w * (1.0f / LOG2E), cc = Bc.x * (2.0f / LOG2E);
@@ -265,31 +287,12 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     } else {
       for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
     }
-    __syncthreads();
-    // flush: 4 Gaussians per wave instruction, 16 lanes = one 64-byte row
-    const int f = lane & 15;
-    const bool field_used =
-        (f < GSR_GR_COLOR + CH) || (ABSGRAD && (f == GSR_GR_ABS || f == GSR_GR_ABS + 1));
-    for (int j0 = 0; j0 < n; j0 += 4) {
-      const int j = j0 + (lane >> 4);
-      if (j < n && field_used && sG[j][15] != 0.f) {
-        const int g = sId[buf][j];
-        float val = sG[j][f];
-        if (f < 2) {   // v_xy = conic * (first moments): row holds (m_x, m_y)
-          const float4 Aj = sRec[0][j];
-          const float4 Bj = sRec[1][j];
-          const float ca = Aj.z * (2.0f / LOG2E), cb = Aj.w * (1.0f / LOG2E),
-                      cc = Bj.x * (2.0f / LOG2E);
-          const float mx_ = sG[j][0], my_ = sG[j][1];
-          val = (f == 0) ? fmaf(ca, mx_, cb * my_) : fmaf(cb, mx_, cc * my_);
-        }
-        if (f == GSR_GR_OPAC) val = -val / sRec[1][j].y;   // row holds sum v_sigma
-        if (f == GSR_GR_CONIC || f == GSR_GR_CONIC + 2) val *= 0.5f;
-        atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, val);
-      }
-    }
-    __syncthreads();
+    n_prev = n;
   }
+  // the last batch's rows: its records are in sRec[buf ^ 1] (buf was flipped on the way out),
+  // its words in the slot before `slot`
+  GSR_WAIT_VMEM();
+  flush(n_prev, sRec[buf ^ 1], sPw[(slot == 0) ? 2 : slot - 1]);
 }
 
 // Test hook for the lane-swap tree (the semantics of v_permlane{16,32}_swap are
@@ -309,19 +312,19 @@ __global__ void debug_tree_reduce8_kernel(const float *__restrict__ in, float *_
 template <int CH>
 static int launch_bwd(int n_tiles, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      const int32_t *tile_order, const int32_t *pair_ids,
                       const float *render_alphas, const int32_t *last_ids,
                       const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *grad_rows, hipStream_t stream) {
   if (absgrad)
     hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), 0, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors,
+                       tile_order, pair_ids, render_alphas, last_ids, v_render_colors,
                        v_render_alphas, grad_rows);
   else
     hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(n_tiles), dim3(64), 0, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
-                       tile_order, flatten_ids, render_alphas, last_ids, v_render_colors,
+                       tile_order, pair_ids, render_alphas, last_ids, v_render_colors,
                        v_render_alphas, grad_rows);
   GSR_CHECK_LAUNCH("rasterize_bwd");
   return GSR_OK;
@@ -341,7 +344,7 @@ extern "C" int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_
 extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds,
                                  int width, int height, int tile_w, int tile_h,
                                  const int32_t *tile_offsets, const int32_t *tile_order,
-                                 const int32_t *flatten_ids, const float *render_alphas,
+                                 const int32_t *pair_ids, const float *render_alphas,
                                  const int32_t *last_ids, const float *v_render_colors,
                                  const float *v_render_alphas, int absgrad, float *grad_rows,
                                  void *stream) {
@@ -357,7 +360,7 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
 #define GSR_BWD_CASE(K)                                                                         \
   case K:                                                                                       \
     return gsr::launch_bwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
-                              tile_offsets, tile_order, flatten_ids, render_alphas, last_ids,   \
+                              tile_offsets, tile_order, pair_ids, render_alphas, last_ids,      \
                               v_render_colors, v_render_alphas, absgrad, grad_rows, st);
   switch (CH) {
     GSR_BWD_CASE(1)

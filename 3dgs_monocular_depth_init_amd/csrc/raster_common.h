@@ -1,14 +1,24 @@
-// raster_common.h -- pieces shared by the compositing forward and backward.
+// raster_common.h -- pieces shared by the tile-list builder and the compositing kernels.
 //
-// Wave/tile shape (both kernels): ONE wave64 per 16x16 tile. The tile is cut
+// Wave/tile shape (both compositing kernels): ONE wave64 per 16x16 tile. The tile is cut
 // into four 8x8 quadrants; lane l owns pixel (l & 7, l >> 3) of EVERY quadrant
-// (4 pixels per lane). For each Gaussian of the tile list the staging lane
-// pre-computes a 4-bit quadrant mask by an exact ellipse-vs-rectangle test
-// (min of sigma over the quadrant's pixel centres <= ln(255*opacity), i.e. at
-// least one pixel could reach alpha >= 1/255). The mask is wave-uniform, so
-// the per-quadrant body is skipped with SCALAR branches: with ~5 px radii a
-// Gaussian touches ~2 of the 4 quadrants, which halves the VALU work without
-// changing any result (a skipped quadrant has alpha < 1/255 everywhere).
+// (4 pixels per lane). Every (tile, Gaussian) pair of the tile lists carries a 4-bit
+// quadrant mask from an exact ellipse-vs-rectangle test (min of sigma over the
+// quadrant's pixel centres <= ln(255*opacity), i.e. at least one pixel could reach
+// alpha >= 1/255). The mask is wave-uniform, so the per-quadrant body is skipped with
+// SCALAR branches: with ~6 px radii a Gaussian touches 1.8 of the 4 quadrants, which
+// halves the VALU work without changing any result (a skipped quadrant has
+// alpha < 1/255 everywhere).
+//
+// Round 3: the mask is computed ONCE per pair, where the pair is created (the emit pass
+// of isect_bucket.hip, or gsr_pair_masks for lists built elsewhere), and travels in the
+// top four bits of the pair word the compositing kernels read:
+//     pair_ids[i] = g | mask << 28          (g = camera * N + Gaussian < 2^28)
+// Before, both compositing kernels re-derived it while staging each batch (four
+// min_sigma_rect evaluations per pair and kernel, ~14 live registers that pushed the
+// forward into scratch and made it wait for its own prefetch: profiles/r03_fwd_timeline_before.json).
+// With `tight` lists a pair whose mask is 0 is never emitted at all (17.5 % of the c4 pairs,
+// profiles/r03_pair_stats.jsonl).
 #pragma once
 #include "common.h"
 #include "gs_math.h"
@@ -18,18 +28,13 @@ namespace gsr {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PIX_DONE = 1.0e18f;   // pixel x of a finished / outside pixel: sigma -> huge, alpha -> 0
 
-template <int CH>
-struct TileRec {      // LDS image of one staged Gaussian
-  float4 a;           // mx, my, ha = 0.5*a*log2e, bb = b*log2e
-  float4 b;           // hc = 0.5*c*log2e, opacity, col0, col1
-  float4 c;           // col2, col3, col4, quadrant mask (int bits)
-};
+constexpr int PAIR_MASK_SHIFT = 28;
+constexpr uint32_t PAIR_ID_MASK = 0x0fffffffu;
 
 // sigma' = log2(e) * sigma = ha*dx^2 + bb*dx*dy + hc*dy^2, evaluated identically in
 // forward and backward as dx*(ha*dx + B) + C with the row terms B = bb*dy, C = hc*dy*dy:
 // the two quadrants of a row share dy, so B and C cost 3 VALU per (Gaussian, row) and
-// sigma 2 per pixel (the kernels issue one VALU instruction per 4 cycles per SIMD and
-// are bound by exactly that, so instruction counts are what the layout is chosen for).
+// sigma 2 per pixel.
 __device__ __forceinline__ void sigma_row_terms(float bb, float hc, float dy, float &B, float &C) {
   B = bb * dy;
   C = (hc * dy) * dy;
@@ -42,66 +47,160 @@ __device__ __forceinline__ float with_sign_of(float ov, float sigma) {
   return __uint_as_float(__float_as_uint(ov) | (__float_as_uint(sigma) & 0x80000000u));
 }
 
-// min over the rectangle of pixel centres [x0,x1]x[y0,y1] of
-// sigma(d) = 0.5*(a dx^2 + c dy^2) + b dx dy, d = mean - pixel.
-__device__ __forceinline__ float min_sigma_rect(float a, float b, float c, float mx, float my,
-                                                float x0, float x1, float y0, float y1) {
-  // (x1 - x0 and y1 - y0 are compile-time constants at the call sites: written so that the
-  // wave-uniform x0 / y0 are each used once and can stay in scalar registers)
-  const float dxhi = mx - x0, dyhi = my - y0;
-  const float dxlo = dxhi - (x1 - x0), dylo = dyhi - (y1 - y0);
-  if (dxlo <= 0.f && dxhi >= 0.f && dylo <= 0.f && dyhi >= 0.f) return 0.f;
-  auto sig = [&](float dx, float dy) { return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy; };
-  const float ic = 1.0f / c, ia = 1.0f / a;
-  float m = sig(dxlo, fminf(fmaxf(-b * dxlo * ic, dylo), dyhi));
-  m = fminf(m, sig(dxhi, fminf(fmaxf(-b * dxhi * ic, dylo), dyhi)));
-  m = fminf(m, sig(fminf(fmaxf(-b * dylo * ia, dxlo), dxhi), dylo));
-  m = fminf(m, sig(fminf(fmaxf(-b * dyhi * ia, dxlo), dxhi), dyhi));
-  return m;
-}
-
-// Packed per-(camera,Gaussian) compositing record, one 64-byte row (= one cache
-// line / one fabric request per gather instead of four scattered arrays):
-//   [0] mx  my  conic.a conic.b   [1] conic.c opacity col0 col1   [2] col2 col3 col4 -
-// written by gsr_project_fwd (or gsr_pack_records for caller-supplied colours).
-constexpr int REC_FLOATS = 16;
-
-// The gather and the LDS image are split so that the kernels can software-pipeline:
-// the loads of batch b+1 are issued before the compositing loop of batch b and only
-// consumed (make_rec) after it, so their latency is covered by the wave's own work.
-template <int CH>
-struct RawRec {
-  float4 r0, r1, r2;
-};
-
-template <int CH>
-__device__ __forceinline__ void load_raw(int g, const float *__restrict__ records, RawRec<CH> &w) {
-  const float4 *row = reinterpret_cast<const float4 *>(records + (int64_t)g * REC_FLOATS);
-  w.r0 = row[0];
-  w.r1 = row[1];
-  if (CH > 3) w.r2 = row[2];
-  else if (CH > 2) w.r2.x = records[(int64_t)g * REC_FLOATS + 8];
-}
-
-// Build the LDS image of a gathered record for the tile at (tx0, ty0).
-template <int CH>
-__device__ __forceinline__ void make_rec(const RawRec<CH> &w, float tx0, float ty0, TileRec<CH> &r) {
-  const float4 r0 = w.r0, r1 = w.r1;
-  const float a = r0.z, b = r0.w, c = r1.x, op = r1.y;
-  // alpha >= 1/255  <=>  sigma <= ln(255*op); small margin keeps the test conservative
+// alpha >= 1/255  <=>  sigma <= ln(255*op); the small margin keeps the test conservative
+__device__ __forceinline__ float alpha_tau(float op) {
   const float tau = logf(op * 255.0f);
-  const float tau_m = tau + 1e-4f * (1.0f + fabsf(tau));
+  return tau + 1e-4f * (1.0f + fabsf(tau));
+}
+
+// 4-bit quadrant mask of a Gaussian against the tile whose top-left pixel is (tx0, ty0): bit q set
+// <=> some pixel centre of quadrant q (x half q & 1, y half q >> 1) can reach alpha >= 1/255, i.e.
+// min over the quadrant's rectangle of pixel centres of sigma(d) = (a dx^2 + c dy^2)/2 + b dx dy is
+// <= tau_m. sigma is convex with its minimum at the mean, so over a rectangle that does not contain
+// the mean it is minimal on the edge(s) FACING the mean: one vertical edge when the mean lies beside
+// the rectangle, one horizontal edge when above / below, both at a corner. Along a vertical edge at
+// offset dx the minimum over dy is at dy* = -b dx / c clamped to the edge, with value
+// kx dx^2 + c/2 (dy - dy*)^2, kx = (a - b^2/c)/2; likewise for horizontal edges. The per-Gaussian
+// constants are set up once (PairConic), the x- and y-halves of the tile share their edge terms.
+struct PairConic {
+  float mx, my, ha, hc, sx, sy, kx, ky, tau_m;   // ha = a/2, hc = c/2, sx = -b/a, sy = -b/c
+};
+__device__ __forceinline__ PairConic make_pair_conic(float mx, float my, float a, float b, float c,
+                                                     float op) {
+  PairConic p;
+  const float ia = __builtin_amdgcn_rcpf(a), ic = __builtin_amdgcn_rcpf(c);
+  p.mx = mx;
+  p.my = my;
+  p.ha = 0.5f * a;
+  p.hc = 0.5f * c;
+  p.sx = -b * ia;
+  p.sy = -b * ic;
+  p.kx = 0.5f * (a - b * b * ic);
+  p.ky = 0.5f * (c - b * b * ia);
+  p.tau_m = alpha_tau(op);
+  return p;
+}
+__device__ __forceinline__ int pair_quadrant_mask(const PairConic &p, float tx0, float ty0) {
+  // per half h (0: pixels 0..7, 1: pixels 8..15) and axis: offsets of the mean from the first and
+  // last pixel centre, whether the mean lies inside the half's span, and the facing edge's offset
+  float lo[2][2], hi[2][2], de[2][2];
+  bool in[2][2];
+#pragma unroll
+  for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float first = (ax == 0 ? tx0 : ty0) + (8.f * (float)h + 0.5f);
+      hi[ax][h] = (ax == 0 ? p.mx : p.my) - first;
+      lo[ax][h] = hi[ax][h] - 7.f;
+      in[ax][h] = lo[ax][h] * hi[ax][h] <= 0.f;
+      de[ax][h] = hi[ax][h] < 0.f ? hi[ax][h] : lo[ax][h];
+    }
+  // edge terms shared by the two quadrants of a column (vertical edges) / row (horizontal edges)
+  float vp[2], vk[2], hp[2], hk[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    vp[h] = p.sy * de[0][h];              // dy* on the vertical edge of x-half h
+    vk[h] = p.kx * de[0][h] * de[0][h];
+    hp[h] = p.sx * de[1][h];              // dx* on the horizontal edge of y-half h
+    hk[h] = p.ky * de[1][h] * de[1][h];
+  }
   int qmask = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float x0 = tx0 + (8.f * (float)(q & 1) + 0.5f), y0 = ty0 + (8.f * (float)(q >> 1) + 0.5f);
-    const float ms = min_sigma_rect(a, b, c, r0.x, r0.y, x0, x0 + 7.f, y0, y0 + 7.f);
-    qmask |= (ms <= tau_m) ? (1 << q) : 0;
+    const int xh = q & 1, yh = q >> 1;
+    const float tv = __builtin_amdgcn_fmed3f(vp[xh], lo[1][yh], hi[1][yh]) - vp[xh];
+    const float sv = fmaf(p.hc * tv, tv, vk[xh]);
+    const float th = __builtin_amdgcn_fmed3f(hp[yh], lo[0][xh], hi[0][xh]) - hp[yh];
+    const float sh = fmaf(p.ha * th, th, hk[yh]);
+    // inside along x: only the horizontal edge faces the mean; inside along y: only the vertical one
+    float m = fminf(in[0][xh] ? 3.0e38f : sv, in[1][yh] ? 3.0e38f : sh);
+    m = (in[0][xh] && in[1][yh]) ? 0.f : m;
+    qmask |= (m <= p.tau_m) ? (1 << q) : 0;
   }
-  r.a = make_float4(r0.x, r0.y, 0.5f * a * LOG2E, b * LOG2E);
-  r.b = make_float4(0.5f * c * LOG2E, op, r1.z, r1.w);
-  r.c = make_float4(CH > 2 ? w.r2.x : 0.f, CH > 3 ? w.r2.y : 0.f, CH > 4 ? w.r2.z : 0.f,
-                    __int_as_float(qmask));
+  return qmask;
+}
+
+// Packed per-(camera,Gaussian) compositing record, one 64-byte row (= one cache line / one
+// fabric request per gather), written by gsr_project_fwd or gsr_pack_records with the conic
+// ALREADY in the units the compositing loops use:
+//   [0] mx  my  ha  bb    [1] hc  opacity  col0  col1    [2] col2  col3  col4  -    [3] unused
+//   ha = 0.5*a*log2(e), bb = b*log2(e), hc = 0.5*c*log2(e)
+// The compositing kernels copy rows into LDS with LDS-DMA (no registers, no arithmetic).
+constexpr int REC_FLOATS = 16;
+__device__ __forceinline__ void write_record(float *__restrict__ records, int64_t g, float mx, float my,
+                                             float a, float b, float c, float op, const float col[5]) {
+  float4 *row = reinterpret_cast<float4 *>(records + g * REC_FLOATS);
+  row[0] = make_float4(mx, my, 0.5f * a * LOG2E, b * LOG2E);
+  row[1] = make_float4(0.5f * c * LOG2E, op, col[0], col[1]);
+  row[2] = make_float4(col[2], col[3], col[4], 0.f);
+}
+
+// LDS image of a batch: RBATCH rows of 64 bytes, double buffered. One LDS-DMA instruction
+// (global_load_lds_dwordx4: 64 lanes x 16 B, lane-linear in LDS) moves 16 whole rows:
+// lanes 4r .. 4r+3 fetch the four 16-byte chunks of row r.
+constexpr int RBATCH = 32;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// A value the compiler must treat as freshly produced here: keeps loop-invariant address
+// arithmetic of rarely executed paths (and of the once-per-batch staging) from being hoisted
+// into registers that stay live across the compositing loops.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// The DMAs are asm statements on purpose: hipcc counts a __builtin_amdgcn_global_load_lds as an LDS
+// store and, unable to prove that the buffer being filled is not the one being read, drains it
+// (s_waitcnt vmcnt(0)) before the next LDS read -- i.e. right after issuing it. An asm statement is
+// absent from its bookkeeping; the kernels wait for the data themselves (GSR_WAIT_VMEM at the top of
+// the batch that reads it). M0 (the LDS destination base) is saved and restored inside the
+// statement (cdna_hip_programming.md section 5.7). Only ACTIVE lanes transfer; lane l writes
+// lds_dst + l * (16 or 4) bytes.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void_t *)p);
+}
+__device__ __forceinline__ void dma_16B(const void *src_lane, const void *lds_dst_uniform) {
+  const uint32_t dst = lds_addr(lds_dst_uniform);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src_lane), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void dma_4B(const void *src_lane, const void *lds_dst_uniform) {
+  const uint32_t dst = lds_addr(lds_dst_uniform);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src_lane), "s"(dst)
+      : "memory");
+}
+#define GSR_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// Pair words travel through LDS too (a 3-slot ring of 32 words, filled two batches ahead): held in
+// registers across the compositing loop they were what the register allocator spilled first -- and
+// a spill of a just-loaded register is a wait for it. Slot (batch number % 3), word r = the batch's
+// r-th pair: list position p0 + r*dir clamped to [lo, hi] (dir = +1 forward, -1 backward; clamped
+// entries repeat a valid id and are never composited: the loops stop at the batch's own length).
+constexpr int PW_SLOTS = 3;
+template <int DIR>
+__device__ __forceinline__ void dma_pair_words(const int32_t *__restrict__ pair_ids, int p0, int lo, int hi,
+                                               int lane_, uint32_t *slot) {
+  const int lane = opaque(lane_);
+  if (lane < RBATCH) dma_4B(pair_ids + min(max(p0 + DIR * lane, lo), hi), slot);
+}
+// Stage the 32 records named by a slot of pair words into dst[32][4].
+__device__ __forceinline__ void dma_stage_batch(const float *__restrict__ records, const uint32_t *slot,
+                                                int lane_, float4 (*dst)[4]) {
+  const int lane = opaque(lane_);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t id = slot[16 * h + (lane >> 2)] & PAIR_ID_MASK;
+    dma_16B(records + (int64_t)id * REC_FLOATS + 4 * (lane & 3), &dst[16 * h][0]);
+  }
 }
 
 }  // namespace gsr

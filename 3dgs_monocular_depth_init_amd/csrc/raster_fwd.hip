@@ -6,45 +6,33 @@
 // 4x fewer LDS broadcast reads per pixel-Gaussian pair than one pixel per thread,
 // no cross-wave barriers, wave-uniform skips per quadrant and per row of
 // quadrants). The tile's depth-sorted list is streamed through LDS in batches of
-// 64 Gaussians; the gather of batch k+1 is in flight while batch k is composited.
-// 64 VGPRs -> 8 waves/SIMD, so that all 8160 tiles of a 1080p frame are resident
-// at once (measured: 0.178 ms against 0.19 ms at 5-7 waves/SIMD, where a second
-// round of tiles trails the first).
+// 32 Gaussians: the 64-byte records of batch k+1 are copied global -> LDS by LDS-DMA
+// (no registers, no arithmetic: the records are stored in the loop's own units and
+// the quadrant masks arrive with the pair words) while batch k is composited.
+// Round 3 rewrite: the round-2 kernel re-derived the masks while staging
+// (min_sigma_rect x 4 per pair), which cost 18 % of the wave time and, through its
+// register pressure at the 64-VGPR / 8-waves budget, put the prefetched record
+// registers into scratch -- every batch then waited for its own prefetch
+// (profiles/r03_fwd_timeline_before.json).
 #include <type_traits>
 
 #include "raster_common.h"
 
 namespace gsr {
 
-#ifdef GSR_FWD_TIMELINE
-// Diagnostic build only (tools/fwd_timeline.py): per tile, cycles spent in the segments of a
-// batch, summed over the tile's batches: [0] waiting for the gathered records, [1] building
-// the LDS image (make_rec, ds_write, barrier), [2] issuing the next batch's loads, [3] the
-// compositing loop, [4] whole kernel, [5] batches, [6] list length. s_memtime stamps, as
-// cdna_hip_programming.md section 7 prescribes (one asm statement with its lgkmcnt(0),
-// sched barriers around it); the values leave through a buffer nothing else reads.
-__device__ unsigned long long *g_fwd_timeline = nullptr;
-#define GSR_STAMP(t)                                                        \
-  do {                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-  } while (0)
-#endif
-
 template <int CH>
-__global__ void __launch_bounds__(64, (CH <= 3) ? 8 : 5)
+__global__ void __launch_bounds__(64, (CH <= 3) ? 8 : 6)
 raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                   const float *__restrict__ backgrounds, int width, int height, int tile_w,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ tile_order,
-                  const int32_t *__restrict__ flatten_ids, float *__restrict__ render_colors,
+                  const int32_t *__restrict__ pair_ids, float *__restrict__ render_colors,
                   float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
-  // staged batch: [0] = {mx, my, ha, bb}, [1] = {hc, opacity, col0, col1},
-  // [2] = {col2, col3, col4, quadrant mask}. 3 KB per wave; a single buffer is enough
-  // because the workgroup IS one wave: its LDS writes for the next batch follow its reads
-  // of the current one in program order.
-  __shared__ float4 sRec[1][3][64];
+  // staged batches: row r = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | -}.
+  // 2 x 2 KB per wave; the workgroup IS one wave, so no barriers: the DMA into buffer (k+1)&1 is
+  // issued after the loop over batch k-1 has consumed its last read of that buffer.
+  __shared__ __attribute__((aligned(16))) float4 sRec[2][RBATCH][4];
+  __shared__ uint32_t sPw[PW_SLOTS][RBATCH];
 
   if ((int)blockIdx.x >= n_tiles) return;
   const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
@@ -55,14 +43,9 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   const int tx0 = tx * GSR_TILE, ty0 = ty * GSR_TILE;
-  // tile origin as floats held in SCALAR registers (wave-uniform; a VGPR copy would be
-  // hoisted out of the loops and cost the compositing loops registers)
-  const float ftx0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)tx0)));
-  const float fty0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)ty0)));
 
   // pixel q of this lane: (tx0 + 8*(q&1) + lx, ty0 + 8*(q>>1) + ly)
   float px[4], py[2], T[4], acc[4][CH];
-  int last[4];
   unsigned outside = 0;
   py[0] = (float)(ty0 + ly) + 0.5f;
   py[1] = py[0] + 8.0f;
@@ -71,7 +54,6 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
     px[q] = (float)x + 0.5f;
     T[q] = 1.0f;
-    last[q] = 0x7fffffff;   // "never terminated": resolved to the end of the list at the end
     if (x >= width || y >= height) {
       outside |= 1u << q;
       px[q] = PIX_DONE;
@@ -79,131 +61,101 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[q][k] = 0.f;
   }
+  // linear pixel index of quadrant q's pixel of this lane; recomputed where it is needed (a rare
+  // path and the epilogue) instead of living in registers across the loops
+  auto pix_of = [&](int q) {
+    const int l = opaque(lane);
+    return ((int64_t)cam * height + (ty0 + 8 * (q >> 1) + (l >> 3))) * width + (tx0 + 8 * (q & 1) + (l & 7));
+  };
 
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
-  // software pipeline: ids two batches ahead, record rows one batch ahead (in flight
-  // during the compositing loop), LDS image built after the loop
-  RawRec<CH> raw;
-  TileRec<CH> rec;
-  // (loads are unconditional with clamped indices: a predicated load would merge old and
-  // new register values, and the copies that merge needs wait for the load right away)
-  if (e <= s) {
-    raw.r0 = raw.r1 = raw.r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-    load_raw<CH>(flatten_ids[min(s + lane, e - 1)], records, raw);
-  }
-  int id_next = (e > s) ? flatten_ids[min(s + 64 + lane, e - 1)] : 0;
-  constexpr int buf = 0;
+  const int last = e - 1;
   unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
-#ifdef GSR_FWD_TIMELINE
-  unsigned long long tl_t0, tl_a, tl_b, tl_c, tl_d, tl_e;
-  unsigned long long tl_wait = 0, tl_rec = 0, tl_issue = 0, tl_loop = 0, tl_batches = 0;
-  GSR_STAMP(tl_t0);
-#endif
-  for (int base = s; base < e; base += 64) {
-    // drop quadrants whose 64 pixels are all finished (or outside the image)
+  if (e > s) {
+    // pipeline: pair words two batches ahead, records one batch ahead, both by LDS-DMA
+    dma_pair_words<1>(pair_ids, s, s, last, lane, sPw[0]);
+    dma_pair_words<1>(pair_ids, s + RBATCH, s, last, lane, sPw[1]);
+    GSR_WAIT_VMEM();
+    dma_stage_batch(records, sPw[0], lane, sRec[0]);
+    int buf = 0, slot = 0;   // slot = batch number % 3
+    for (int base = s; base < e; base += RBATCH, buf ^= 1, slot = (slot == 2) ? 0 : slot + 1) {
+      // drop quadrants whose 64 pixels are all finished (or outside the image)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (!__any(px[q] != PIX_DONE)) live &= ~(1u << q);
-    if (live == 0) break;
-    const int n = min(64, e - base);
-    bool can_clamp = false;   // opacity > 0.999: alpha may hit the clamp
-#ifdef GSR_FWD_TIMELINE
-    GSR_STAMP(tl_a);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GSR_STAMP(tl_b);
-#endif
-    if (lane < n) {
-      make_rec<CH>(raw, ftx0, fty0, rec);
-      can_clamp = rec.b.y > gs::ALPHA_MAX;
-      sRec[buf][0][lane] = rec.a;
-      sRec[buf][1][lane] = rec.b;
-      sRec[buf][2][lane] = rec.c;
-    }
-    __syncthreads();
-#ifdef GSR_FWD_TIMELINE
-    GSR_STAMP(tl_c);
-#endif
-    load_raw<CH>(id_next, records, raw);
-    id_next = flatten_ids[min(base + 128 + lane, e - 1)];
-#ifdef GSR_FWD_TIMELINE
-    GSR_STAMP(tl_d);
-#endif
+      for (int q = 0; q < 4; ++q)
+        if (!__any(px[q] != PIX_DONE)) live &= ~(1u << q);
+      if (live == 0) break;
+      const int n = min(RBATCH, e - base);
+      GSR_WAIT_VMEM();                       // this batch's records and the next batch's words are in LDS
+      if (base + RBATCH < e) {
+        const int s1 = (slot == 2) ? 0 : slot + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
+        dma_stage_batch(records, sPw[s1], lane, sRec[buf ^ 1]);
+        dma_pair_words<1>(pair_ids, base + 2 * RBATCH, s, last, lane, sPw[s2]);
+      }
+      const uint32_t pw = sPw[slot][lane & 31];   // lane j < n: pair j's word (mask in the top bits)
+      const float4(*rec)[4] = sRec[buf];
+      // opacity > 0.999 somewhere in the batch: alpha may hit the clamp
+      const bool can_clamp = (lane < n) && rec[lane & 31][1].y > gs::ALPHA_MAX;
 
-    // One Gaussian against the tile. NOCLAMP (wave-uniform per batch): no opacity of the
-    // batch exceeds 0.999, so min(0.999, .) is compiled out.
-    auto composite = [&](auto noclamp_tag, int j) {
-      constexpr bool NOCLAMP = decltype(noclamp_tag)::value;
-      const unsigned qm =
-          (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(sRec[buf][2][j].w)) & live;
-      if (qm == 0) return;
-      const float4 Ac = sRec[buf][0][j], Bc = sRec[buf][1][j];
-      float col[CH];
-      col[0] = Bc.z;
-      if (CH > 1) col[1] = Bc.w;
-      if (CH > 2) col[2] = sRec[buf][2][j].x;
-      if (CH > 3) col[3] = sRec[buf][2][j].y;
-      if (CH > 4) col[4] = sRec[buf][2][j].z;
+      // One Gaussian against the tile. NOCLAMP (wave-uniform per batch): no opacity of the
+      // batch exceeds 0.999, so min(0.999, .) is compiled out.
+      auto composite = [&](auto noclamp_tag, int j) {
+        constexpr bool NOCLAMP = decltype(noclamp_tag)::value;
+        const unsigned qm =
+            ((unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT) & live;
+        if (qm == 0) return;
+        const float4 Ac = rec[j][0], Bc = rec[j][1];
+        float col[CH];
+        col[0] = Bc.z;
+        if (CH > 1) col[1] = Bc.w;
+        if (CH > 2) col[2] = rec[j][2].x;
+        if (CH > 3) col[3] = rec[j][2].y;
+        if (CH > 4) col[4] = rec[j][2].z;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (qm & (3u << (2 * r))) {   // scalar: this row of quadrants is touched
-          float Br, Cr;
-          sigma_row_terms(Ac.w, Bc.x, Ac.y - py[r], Br, Cr);
+        for (int r = 0; r < 2; ++r) {
+          if (qm & (3u << (2 * r))) {   // scalar: this row of quadrants is touched
+            float Br, Cr;
+            sigma_row_terms(Ac.w, Bc.x, Ac.y - py[r], Br, Cr);
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q = 2 * r + h;
-            if (qm & (1u << q)) {   // scalar branch
-              const float dx = Ac.x - px[q];
-              const float sg = sigma_l2(Ac.z, dx, Br, Cr);
-              const float ov = Bc.y * __builtin_amdgcn_exp2f(-sg);
-              // valid <=> sigma >= 0 and alpha >= 1/255 (<=> ov >= 1/255): one compare
-              const bool ok = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
-              float a = ok ? (NOCLAMP ? ov : fminf(gs::ALPHA_MAX, ov)) : 0.f;
-              float nT = fmaf(-a, T[q], T[q]);
-              if (__any(nT <= gs::T_THRESHOLD)) {   // rare: a pixel finishes at this Gaussian
-                const bool stop = nT <= gs::T_THRESHOLD;   // only possible when ok
-                a = stop ? 0.f : a;
-                nT = stop ? T[q] : nT;
-                px[q] = stop ? PIX_DONE : px[q];
-                last[q] = stop ? base + j - 1 : last[q];   // this one is NOT blended
+            for (int h = 0; h < 2; ++h) {
+              const int q = 2 * r + h;
+              if (qm & (1u << q)) {   // scalar branch
+                const float dx = Ac.x - px[q];
+                const float sg = sigma_l2(Ac.z, dx, Br, Cr);
+                const float ov = Bc.y * __builtin_amdgcn_exp2f(-sg);
+                // valid <=> sigma >= 0 and alpha >= 1/255 (<=> ov >= 1/255): one compare
+                const bool ok = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
+                float a = ok ? (NOCLAMP ? ov : fminf(gs::ALPHA_MAX, ov)) : 0.f;
+                float nT = fmaf(-a, T[q], T[q]);
+                if (__any(nT <= gs::T_THRESHOLD)) {   // rare: a pixel finishes at this Gaussian
+                  const bool stop = nT <= gs::T_THRESHOLD;   // only possible when ok
+                  a = stop ? 0.f : a;
+                  nT = stop ? T[q] : nT;
+                  px[q] = stop ? PIX_DONE : px[q];
+                  // this Gaussian is NOT blended: the pixel's last list position is the one before
+                  if (stop) last_ids[pix_of(q)] = base + j - 1;
+                }
+                const float w = a * T[q];
+                T[q] = nT;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) acc[q][k] = fmaf(col[k], w, acc[q][k]);
               }
-              const float w = a * T[q];
-              T[q] = nT;
-#pragma unroll
-              for (int k = 0; k < CH; ++k) acc[q][k] = fmaf(col[k], w, acc[q][k]);
             }
           }
         }
+      };
+      if (!__any(can_clamp)) {
+        for (int j = 0; j < n; ++j) composite(std::true_type{}, j);
+      } else {
+        for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
       }
-    };
-    if (!__any(can_clamp)) {
-      for (int j = 0; j < n; ++j) composite(std::true_type{}, j);
-    } else {
-      for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
     }
-#ifdef GSR_FWD_TIMELINE
-    GSR_STAMP(tl_e);
-    tl_wait += tl_b - tl_a;
-    tl_rec += tl_c - tl_b;
-    tl_issue += tl_d - tl_c;
-    tl_loop += tl_e - tl_d;
-    tl_batches += 1;
-#endif
+    GSR_WAIT_VMEM();   // a DMA issued for a batch the early exit skipped must land before the wave ends
   }
-#ifdef GSR_FWD_TIMELINE
-  GSR_STAMP(tl_e);
-  if (g_fwd_timeline && lane == 0) {
-    unsigned long long *o = g_fwd_timeline + 8 * (size_t)blockIdx.x;
-    o[0] = tl_wait; o[1] = tl_rec; o[2] = tl_issue; o[3] = tl_loop;
-    o[4] = tl_e - tl_t0; o[5] = tl_batches; o[6] = (unsigned long long)(e - s); o[7] = tl_t0;
-  }
-#endif
 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if ((outside >> q) & 1u) continue;
-    const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
-    const int64_t pix = ((int64_t)cam * height + y) * width + x;
+    const int64_t pix = pix_of(q);
     float *out = render_colors + pix * CH;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -212,21 +164,21 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
       out[k] = v;
     }
     render_alphas[pix] = 1.0f - T[q];
-    // list position after which nothing is blended into this pixel: where it terminated, else
-    // the end of the tile's list (the backward re-tests alpha >= 1/255 per pair itself, so the
-    // exact position of the last contributor is not needed and not tracked)
-    last_ids[pix] = (last[q] == 0x7fffffff) ? e - 1 : last[q];
+    // list position after which nothing is blended into this pixel: where it terminated (stored
+    // at that moment), else the end of the tile's list (the backward re-tests alpha >= 1/255 per
+    // pair itself, so the exact position of the last contributor is not needed and not tracked)
+    if (px[q] != PIX_DONE) last_ids[pix] = last;
   }
 }
 
 template <int CH>
 static int launch_fwd(int n_tiles, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids, float *render_colors,
+                      const int32_t *tile_order, const int32_t *pair_ids, float *render_colors,
                       float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), 0, stream, n_tiles, records,
                      backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
-                     flatten_ids, render_colors, render_alphas, last_ids);
+                     pair_ids, render_colors, render_alphas, last_ids);
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
 }
@@ -243,21 +195,11 @@ pack_records_kernel(int64_t total, int N, int CH, const float *__restrict__ mean
   const float *cl = colors + g * color_stride;
   float c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < CH; ++k) c[k] = cl[k];
-  float4 *row = reinterpret_cast<float4 *>(records + g * REC_FLOATS);
-  row[0] = make_float4(means2d[g * 2], means2d[g * 2 + 1], conics[g * 3], conics[g * 3 + 1]);
-  row[1] = make_float4(conics[g * 3 + 2], opacities[opac_per_camera ? g : (g % N)], c[0], c[1]);
-  row[2] = make_float4(c[2], c[3], c[4], 0.f);
+  write_record(records, g, means2d[g * 2], means2d[g * 2 + 1], conics[g * 3], conics[g * 3 + 1],
+               conics[g * 3 + 2], opacities[opac_per_camera ? g : (g % N)], c);
 }
 
 }  // namespace gsr
-
-#ifdef GSR_FWD_TIMELINE
-extern "C" int gsr_debug_set_fwd_timeline(void *buf) {
-  unsigned long long *p = (unsigned long long *)buf;
-  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_fwd_timeline), &p, sizeof(p)));
-  return GSR_OK;
-}
-#endif
 
 extern "C" int gsr_pack_records(int C, int N, int CH, const float *means2d, const float *conics,
                                 const float *colors, int color_stride, const float *opacities,
@@ -276,7 +218,7 @@ extern "C" int gsr_pack_records(int C, int N, int CH, const float *means2d, cons
 extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds,
                                  int width, int height, int tile_w, int tile_h,
                                  const int32_t *tile_offsets, const int32_t *tile_order,
-                                 const int32_t *flatten_ids, float *render_colors,
+                                 const int32_t *pair_ids, float *render_colors,
                                  float *render_alphas, int32_t *last_ids, void *stream) {
   GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
@@ -286,12 +228,13 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
   if (C == 0) return GSR_OK;
   GSR_REQUIRE(tile_offsets && render_colors && render_alphas && last_ids,
               "rasterize_fwd: null pointer");
+  GSR_REQUIRE(((uintptr_t)records & 15) == 0, "rasterize_fwd: records must be 16-byte aligned");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;
 #define GSR_FWD_CASE(K)                                                                         \
   case K:                                                                                       \
     return gsr::launch_fwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
-                              tile_offsets, tile_order, flatten_ids, render_colors,             \
+                              tile_offsets, tile_order, pair_ids, render_colors,                \
                               render_alphas, last_ids, st);
   switch (CH) {
     GSR_FWD_CASE(1)

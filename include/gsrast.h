@@ -197,47 +197,79 @@ int gsr_tile_sort(int n_tiles, const int32_t *tile_offsets,
 /* A5, bucketed variant (isect_bucket.hip): same outputs as count/scan/emit/sort
  * above -- tile_offsets, flatten_ids in (depth, g) order per tile -- without one
  * global atomic per intersection: the first digit is a bucket of 8 tiles along x.
+ * It also produces what the compositing kernels read: pair_ids[i] = g | mask << 28,
+ * mask = the pair's 4-bit quadrant mask (bit q: the ellipse alpha >= 1/255 reaches the
+ * 8x8 quadrant q of the tile; exact test, csrc/raster_common.h).
  *   gsr_bucket_layout : buckets per row (bw) and in total; GSR_ECAPACITY when the
  *                       total exceeds the LDS histogram (8192) -> use the calls above.
- *   gsr_bucket_count  : bucket_counts[n_buckets] (zeroed inside); scan them with
- *                       gsr_isect_scan (its tile_order output = bucket work order).
- *   gsr_bucket_emit   : composite keys (tile-in-bucket | depth | g) into the buckets;
- *                       bucket_cursor[n_buckets] is scratch. Needs C*N < 2^30.
- *   gsr_bucket_sort   : sorts every bucket in LDS, writes flatten_ids[n_isects],
- *                       tile_offsets[n_tiles+1] and (optional) tile_order[n_tiles]. */
+ *   gsr_bucket_count  : bucket_counts[n_buckets] under gsplat's rule (every tile the rectangle
+ *                       mean +- radius touches); also zeroes clear_a / clear_b (the emit
+ *                       pass's cursor and real counts) when given.
+ *   gsr_bucket_emit   : scans the counts (bucket_offsets[n_buckets+1], bucket_order, and the
+ *                       number of reserved slots -> total_host[0]), evaluates the exact pair
+ *                       test and scatters the composite keys (tile-in-bucket | depth | g |
+ *                       mask) into the buckets. Needs C*N < 2^26.
+ *   gsr_bucket_sort   : sorts every bucket in LDS and writes, compacted, flatten_ids[I],
+ *                       pair_ids[I], (optional) keys_sorted[I], tile_offsets[n_tiles+1], the
+ *                       number of listed pairs I -> total_host[0], and (optional)
+ *                       tile_order[n_tiles].
+ * tight = 0: gsplat's lists, bit for bit. tight = 1 (runner.rasterize_splats): pairs whose
+ *   mask is 0 -- no pixel of the tile can reach alpha >= 1/255 -- are not listed; same image
+ *   and gradients, fewer pairs to sort, gather and composite; the slots the count pass had
+ *   reserved for them hold sentinel keys that the sort pass skips.
+ * conics [C,N,3] (natural units), opacities [N] or [C,N]. keys / flatten_ids / pair_ids hold
+ * `capacity` entries (>= the reserved slots, else the lists are truncated: check total_host). */
 int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int *n_buckets_out);
 int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii, int tile_w,
-                     int tile_h, int32_t *bucket_counts,
+                     int tile_h, int32_t *bucket_counts, int32_t *clear_a /* NULL or [n_buckets] */,
+                     int32_t *clear_b /* NULL or [n_buckets] */,
                      int assume_zero /* 1: bucket_counts is already zero, no memset launch */,
                      void *stream);
 int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
-                    int tile_w, int tile_h, const int32_t *bucket_offsets, int32_t *bucket_cursor,
-                    uint64_t *keys, int64_t capacity, int assume_zero /* cursor already zero */,
-                    void *stream);
+                    const float *conics, const float *opacities, int opac_per_camera, int tile_w,
+                    int tile_h, int tight, const int32_t *bucket_counts,
+                    int32_t *bucket_cursor /* [n_buckets], zero */,
+                    int32_t *real_counts /* [n_buckets], zero; out: listed pairs per bucket */,
+                    int32_t *bucket_offsets /* out [n_buckets+1] */,
+                    int32_t *bucket_order /* out [n_buckets] or NULL */,
+                    int32_t *tile_order /* out [n_tiles] or NULL: compositing work order, longest
+                                           bucket first (gsr_bucket_sort can produce the tile-exact one) */,
+                    int32_t *total_host /* NULL or host-visible: reserved slots */, uint64_t *keys,
+                    int64_t capacity, void *stream);
 int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
-                    const int32_t *bucket_order, uint64_t *keys, int32_t *flatten_ids,
-                    int32_t *tile_offsets, int32_t *tile_order,
-                    int64_t capacity /* entries in keys / flatten_ids; offsets are clamped to it */,
+                    const int32_t *bucket_order, const int32_t *real_counts, uint64_t *keys,
+                    uint64_t *keys_sorted /* NULL or [capacity] */, int32_t *flatten_ids,
+                    int32_t *pair_ids, int32_t *tile_offsets, int32_t *tile_order,
+                    int64_t capacity /* entries in keys / flatten_ids / pair_ids; offsets are clamped to it */,
                     int32_t *clear_counts /* NULL, or [n_buckets]: zeroed per bucket on the way out
-                                             (a count / cursor buffer kept across frames) */,
-                    void *stream);
+                                             (the count buffer kept across frames) */,
+                    int32_t *total_host /* NULL or host-visible: listed pairs */, void *stream);
+/* Pair words for lists built by gsr_isect_* / gsr_tile_sort (or by the caller): one launch
+ * that evaluates the quadrant mask of every (tile, Gaussian) entry. Needs C*N < 2^28. */
+int gsr_pair_masks(int C, int N, int tile_w, int tile_h, const int32_t *tile_offsets,
+                   const int32_t *flatten_ids, const float *means2d, const float *conics,
+                   const float *opacities, int opac_per_camera, int32_t *pair_ids, void *stream);
 
-/* Compositing reads ONE packed 64-byte record per (camera, Gaussian):
- *   float[16] = {mx, my, conic a, b | conic c, opacity, col0, col1 | col2, col3, col4, - | pad}
+/* Compositing reads ONE packed 64-byte record per (camera, Gaussian), with the conic in
+ * the units of the compositing loops (ha = a/2 * log2 e, bb = b * log2 e, hc = c/2 * log2 e):
+ *   float[16] = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | pad}
  * gsr_project_fwd writes the records on the SH path; gsr_pack_records builds them
- * from separate arrays (caller-supplied colours; opacities [N] or [C,N]). */
+ * from separate arrays (caller-supplied colours; opacities [N] or [C,N]; natural-unit
+ * conics). records must be 16-byte aligned (rows are copied to LDS by LDS-DMA).
+ * pair_ids: see above (replaces gsplat's flatten_ids at this boundary; the low 28 bits ARE
+ * flatten_ids). Replaces gsplat's rasterize_to_pixels (gs_init_compare/runner.py:341). */
 #define GSR_REC_FLOATS 16
 int gsr_pack_records(int C, int N, int CH, const float *means2d, const float *conics,
                      const float *colors, int color_stride, const float *opacities,
                      int opac_per_camera, float *records, void *stream);
 int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      const int32_t *tile_order, const int32_t *pair_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
                       void *stream);
 int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
-                      const int32_t *tile_order, const int32_t *flatten_ids,
+                      const int32_t *tile_order, const int32_t *pair_ids,
                       const float *render_alphas, const int32_t *last_ids,
                       const float *v_render_colors,
                       const float *v_render_alphas /* NULL = no gradient on the alphas */,

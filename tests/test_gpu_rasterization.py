@@ -34,7 +34,7 @@ def _rel(a, b):
 
 
 def _run_both(R, sc, vm, K, W, H, *, sh_degree=3, render_mode="RGB", backgrounds=None,
-              rasterize_mode="classic", absgrad=False, split=False, seed=11):
+              rasterize_mode="classic", absgrad=False, split=False, seed=11, tight=False):
     """Run oracle (CPU) and HIP on identical inputs with a random cotangent."""
     names = ["means", "quats", "scales", "opacities", "sh0", "shN"]
     cpu = {k: sc[k].clone().requires_grad_(True) for k in names}
@@ -50,7 +50,7 @@ def _run_both(R, sc, vm, K, W, H, *, sh_degree=3, render_mode="RGB", backgrounds
     rc_g, ra_g, meta_g = R.rasterization(
         gpu["means"], gpu["quats"], gpu["scales"], gpu["opacities"], col_g, vm.cuda(), K.cuda(),
         W, H, sh_degree=sh_degree, render_mode=render_mode, backgrounds=bg_g, packed=False,
-        rasterize_mode=rasterize_mode, absgrad=absgrad)
+        rasterize_mode=rasterize_mode, absgrad=absgrad, _tight_tiles=tight)
     meta_g["means2d"].retain_grad()
     g = torch.Generator().manual_seed(seed)
     w_c = torch.randn(rc_c.shape, generator=g)
@@ -319,15 +319,31 @@ def test_bucketed_and_atomic_tile_lists_agree(R):
     tw, th = meta["tile_width"], meta["tile_height"]
     assert R.bucket_layout_ok(3, 20000, tw, th)
     m2d, radii, depths = meta["means2d"].detach(), meta["radii"], meta["depths"].detach()
-    off_b, ord_b, ids_b, _, _ = R.isect_tiles_sorted(m2d, radii, depths, tw, th)
-    off_a, ord_a, ids_a, _, tpg = R.isect_tiles_sorted(m2d, radii, depths, tw, th, want_tiles_per_gauss=True)
+    con, opa = meta["conics"].detach(), meta["opacities"].detach()
+    off_b, ord_b, ids_b, _, _, pairs_b = R.isect_tiles_sorted(m2d, radii, depths, tw, th, conics=con,
+                                                              opacities=opa)
+    off_a, ord_a, ids_a, _, tpg, pairs_a = R.isect_tiles_sorted(m2d, radii, depths, tw, th,
+                                                                want_tiles_per_gauss=True, conics=con,
+                                                                opacities=opa)
     assert torch.equal(off_a, off_b) and torch.equal(ids_a, ids_b)
+    # pair words: the emit pass of the bucketed builder and gsr_pair_masks evaluate the same test
+    assert torch.equal(pairs_a, pairs_b)
+    assert torch.equal(pairs_b & 0x0FFFFFFF, ids_b)
     assert int(tpg.sum()) == ids_a.numel() == int(off_a[-1])
     n_tiles = 3 * tw * th
-    for o in (ord_a, ord_b):                          # both work orders are permutations, longest first
+    for o in (ord_a, ord_b):                          # both work orders are permutations of the tiles
         assert sorted(o.cpu().tolist()) == list(range(n_tiles))
-        lens = (off_a[1:] - off_a[:-1])[o.long()]
-        assert (((lens[:-1] + 31) // 32) >= ((lens[1:] + 31) // 32)).all()
+    lens = (off_a[1:] - off_a[:-1])[ord_a.long()]     # isect.hip: longest tile first (classes of 32)
+    assert (((lens[:-1] + 31) // 32) >= ((lens[1:] + 31) // 32)).all()
+    if not R.EXACT_TILE_ORDER:                        # bucketed: longest BUCKET first (classes of 128)
+        bw = (tw + 7) // 8
+        t = ord_b.long()
+        bucket = (t // tw) * bw + (t % tw) // 8
+        blen = torch.zeros(3 * th * bw, dtype=torch.long, device=t.device).index_add_(
+            0, ((torch.arange(n_tiles, device=t.device) // tw) * bw + (torch.arange(n_tiles, device=t.device) % tw) // 8),
+            (off_a[1:] - off_a[:-1]).long())
+        cls = (blen[bucket] + 127) // 128
+        assert (cls[:-1] >= cls[1:]).all()
     # and against the oracle's stable global sort
     _, ids, flat = O.isect_tiles_fast(m2d.cpu(), radii.cpu(), depths.cpu(), 16, tw, th)
     assert torch.equal(ids_b.cpu(), flat)
@@ -354,3 +370,115 @@ def test_deferred_sync_capacity_overflow_is_rebuilt(R):
         assert torch.equal(m["flatten_ids"], m0["flatten_ids"])
         assert torch.equal(m["isect_offsets"], m0["isect_offsets"])
     assert R._IsectState.capacity[dev] >= n                                 # re-learnt
+
+
+def _torch_min_sigma_rect(a, b, c, mx, my, x0, x1, y0, y1):
+    """fp32 torch restatement of csrc/raster_common.h min_sigma_rect (test infrastructure)."""
+    dxhi, dyhi = mx - x0, my - y0
+    dxlo, dylo = dxhi - (x1 - x0), dyhi - (y1 - y0)
+    inside = (dxlo <= 0) & (dxhi >= 0) & (dylo <= 0) & (dyhi >= 0)
+    sig = lambda dx, dy: 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy
+    cl = lambda v, lo, hi: torch.minimum(torch.maximum(v, lo), hi)
+    m = sig(dxlo, cl(-b * dxlo / c, dylo, dyhi))
+    m = torch.minimum(m, sig(dxhi, cl(-b * dxhi / c, dylo, dyhi)))
+    m = torch.minimum(m, sig(cl(-b * dylo / a, dxlo, dxhi), dylo))
+    m = torch.minimum(m, sig(cl(-b * dyhi / a, dxlo, dxhi), dyhi))
+    return torch.where(inside, torch.zeros_like(m), m)
+
+
+def _pair_tiles(meta):
+    """tile index of every entry of meta's lists."""
+    offs = meta["isect_offsets"].reshape(-1).long()
+    I = meta["flatten_ids"].numel()
+    full = torch.cat([offs, torch.tensor([I], device=offs.device)])
+    return torch.repeat_interleave(torch.arange(offs.numel(), device=offs.device), full[1:] - full[:-1])
+
+
+@pytest.mark.parametrize("n_cams", [1, 2])
+def test_pair_masks_are_exact_and_conservative(R, n_cams):
+    """pair_ids = flatten id | quadrant mask << 28. Every (pixel, Gaussian) contribution the
+    compositing would blend (alpha >= 1/255, evaluated densely in fp64 here) must lie in a
+    quadrant whose bit is set; and the mask must agree with the fp32 restatement of the kernel's
+    ellipse-vs-rectangle test except where that test's value sits within rounding of its threshold."""
+    sc = scenes.make_scene(4000, 21, box=(1.2, 0.8, 0.4), scale_mean=0.02)
+    W, H = 200, 120
+    vm, K = scenes.cameras(list(range(0, 25 * n_cams, 25)), width=W, height=H, f=200.0, dist=2.5)
+    g = {k: sc[k].cuda() for k in ("means", "quats", "scales", "opacities")}
+    col = torch.cat([sc["sh0"], sc["shN"]], 1).cuda()
+    _, _, meta = R.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], col, vm.cuda(),
+                                 K.cuda(), W, H, sh_degree=1, packed=False)
+    ids = meta["flatten_ids"].long()
+    pairs = meta["pair_ids"]
+    assert torch.equal((pairs & 0x0FFFFFFF).long(), ids)
+    mask = (pairs >> 28) & 15
+    tile = _pair_tiles(meta)
+    tw, th = meta["tile_width"], meta["tile_height"]
+    tin = tile % (tw * th)
+    tx0, ty0 = (tin % tw).float() * 16, (tin // tw).float() * 16
+    m2 = meta["means2d"].detach().reshape(-1, 2)[ids]
+    con = meta["conics"].detach().reshape(-1, 3)[ids]
+    op = meta["opacities"].detach().reshape(-1)[ids % 4000]
+    tau = torch.log(op * 255.0)
+    tau_m = tau + 1e-4 * (1 + tau.abs())
+    n_soft = 0
+    for q in range(4):
+        x0, y0 = tx0 + 8.0 * (q & 1) + 0.5, ty0 + 8.0 * (q >> 1) + 0.5
+        ms = _torch_min_sigma_rect(con[:, 0], con[:, 1], con[:, 2], m2[:, 0], m2[:, 1], x0, x0 + 7, y0, y0 + 7)
+        want = ms <= tau_m
+        got = ((mask >> q) & 1).bool()
+        soft = (ms - tau_m).abs() <= 1e-4 * (1 + tau_m.abs())      # within rounding of the threshold
+        assert bool(((want == got) | soft).all())
+        n_soft += int((want != got).sum())
+        # dense fp64 check of conservativeness: max alpha over the quadrant's 64 pixel centres
+        xs = torch.arange(8, device=m2.device, dtype=torch.float64)
+        dx = m2[:, 0, None, None].double() - (x0.double()[:, None, None] + xs[None, None, :])
+        dy = m2[:, 1, None, None].double() - (y0.double()[:, None, None] + xs[None, :, None])
+        a, b, c = (con[:, k, None, None].double() for k in range(3))
+        sigma = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy
+        alpha = op.double()[:, None, None] * torch.exp(-sigma)
+        reach = ((alpha >= 1.0 / 255.0) & (sigma >= 0)).flatten(1).any(1)
+        assert bool((got | ~reach).all()), "a quadrant with alpha >= 1/255 is masked out"
+    assert n_soft <= max(2, ids.numel() // 10000)
+
+
+def test_tight_tile_lists_same_render_and_gradients(R):
+    """`_tight_tiles=True` (runner.rasterize_splats) drops exactly the pairs whose mask is 0; the
+    compositing kernels skip those anyway, so image and alpha are bit-identical, the gradients equal
+    up to the order of the float atomics, and the lists are the default lists minus the dead pairs."""
+    sc, vm, K, W, H = _tiny(N=3000)
+    res = {}
+    for tight in (False, True):
+        cpu, gpu, out_c, out_g = _run_both(R, sc, vm, K, W, H, tight=tight, absgrad=True)
+        if tight:
+            _check(cpu, gpu, out_c, out_g)              # and the oracle agrees with the tight path
+        res[tight] = (gpu, out_g)
+    (g0, (rc0, ra0, m0)), (g1, (rc1, ra1, m1)) = res[False], res[True]
+    assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
+    live = ((m0["pair_ids"] >> 28) & 15) != 0
+    assert int((~live).sum()) > 0, "scene has no dead pair: the test would be vacuous"
+    assert torch.equal(m0["flatten_ids"][live], m1["flatten_ids"])
+    assert torch.equal(m0["pair_ids"][live], m1["pair_ids"])
+    t0 = _pair_tiles(m0)[live]
+    assert torch.equal(t0, _pair_tiles(m1))
+    for k in g0:
+        a, b = g0[k].grad, g1[k].grad
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, k
+    ab0, ab1 = m0["means2d"].absgrad, m1["means2d"].absgrad
+    assert float((ab0 - ab1).abs().max()) <= 1e-5 * float(ab0.abs().max()) + 1e-12
+
+
+def test_tight_lists_long_rectangles(R):
+    """Rectangles of more than 16 tiles take the emit pass's own mask evaluation (no stored word)."""
+    sc = scenes.make_scene(300, 9, box=(0.8, 0.5, 0.3), scale_mean=0.15, scale_std=0.6)
+    W, H = 160, 128
+    vm, K = scenes.cameras([0], width=W, height=H, f=150.0, dist=2.5)
+    g = {k: sc[k].cuda() for k in ("means", "quats", "scales", "opacities")}
+    col = torch.cat([sc["sh0"], sc["shN"]], 1).cuda()
+    args = (g["means"], g["quats"], g["scales"], g["opacities"], col, vm.cuda(), K.cuda(), W, H)
+    rc0, ra0, m0 = R.rasterization(*args, sh_degree=1, packed=False)
+    rc1, ra1, m1 = R.rasterization(*args, sh_degree=1, packed=False, _tight_tiles=True)
+    rad = m0["radii"].reshape(-1, 2).float()
+    assert int(((2 * rad[:, 0] / 16 + 1) * (2 * rad[:, 1] / 16 + 1) > 16).sum()) > 10, "no large rectangle"
+    live = ((m0["pair_ids"] >> 28) & 15) != 0
+    assert torch.equal(m0["pair_ids"][live], m1["pair_ids"])
+    assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
