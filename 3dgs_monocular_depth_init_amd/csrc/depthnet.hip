@@ -192,7 +192,8 @@ gemm_kernel(GemmArgs p) {
 
   const int nk = p.K / BK;
   stage(0, 0);
-  __syncthreads();            // (drains the LDS-DMA: the barrier's fence waits vmcnt(0))
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed: explicit, not left
+  __syncthreads();            // to the barrier's lowering (which happens to wait vmcnt(0) on ROCm 7.2)
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
@@ -211,6 +212,7 @@ gemm_kernel(GemmArgs p) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc[1][1], 0, 0, 0);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as above: not left to the barrier's lowering)
     __syncthreads();          // tile kt+1 has landed, and every wave is done reading tile kt
     buf ^= 1;
   }

@@ -9,7 +9,7 @@
 // camera): every 1024-thread workgroup histograms its slice of the Gaussians in
 // LDS and touches global memory with one atomic per non-empty bucket (~1e5 per
 // frame); each bucket is then sorted INSIDE LDS by the composite key
-//   [63:61] tile-in-bucket | [60:30] depth bits (sign dropped) | [29:4] g | [3:0] quadrant mask
+//   [63:61] tile-in-bucket | [60:30] depth bits (sign dropped) | [29:5] g | [4] clamp | [3:0] quadrant mask
 // which yields, in one pass, the per-tile start offsets and the depth-sorted
 // (ties by g) lists -- the same order as isect.hip / a stable global sort (the mask is a
 // function of (tile, g), so it never decides a comparison).
@@ -32,14 +32,16 @@ constexpr int BK_MAX_BUCKETS = 8192;     // LDS: 2 x 4 B x buckets = 64 KB
 constexpr int BK_SORT_CAP = 8192;        // entries sorted in LDS per bucket (64 KB)
 constexpr int BK_THREADS = 1024;
 
-constexpr int BK_G_BITS = 26;            // g = camera * N + Gaussian < 2^26 in the composite key
-__device__ __forceinline__ uint64_t bk_key(int tloc, float depth, uint32_t g, int mask) {
+constexpr int BK_G_BITS = 25;            // g = camera * N + Gaussian < 2^25 in the composite key
+// low 5 bits: [4] clamp flag (opacity > 0.999), [3:0] quadrant mask -- functions of (tile, g), so they
+// never decide a comparison
+__device__ __forceinline__ uint64_t bk_key(int tloc, float depth, uint32_t g, int mask5) {
   return ((uint64_t)tloc << 61) | ((uint64_t)(__float_as_uint(depth) & 0x7fffffffu) << 30) |
-         ((uint64_t)(g & 0x3ffffffu) << 4) | (uint64_t)(mask & 15);
+         ((uint64_t)(g & 0x1ffffffu) << 5) | (uint64_t)(mask5 & 31);
 }
-__device__ __forceinline__ uint32_t bk_key_g(uint64_t k) { return (uint32_t)(k >> 4) & 0x3ffffffu; }
+__device__ __forceinline__ uint32_t bk_key_g(uint64_t k) { return (uint32_t)(k >> 5) & 0x1ffffffu; }
 __device__ __forceinline__ uint32_t bk_key_pair(uint64_t k) {
-  return bk_key_g(k) | ((uint32_t)(k & 15) << PAIR_MASK_SHIFT);
+  return bk_key_g(k) | ((uint32_t)(k & 15) << PAIR_MASK_SHIFT) | ((k & 16) ? PAIR_CLAMP_BIT : 0u);
 }
 
 // What the exact pair test needs of a projected Gaussian.
@@ -235,7 +237,7 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
         if (TIGHT && m == 0) continue;
         const int b = (c * tile_h + y) * bw + x / BK_TILES;
         const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
-        if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), d, (uint32_t)g, m);
+        if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), d, (uint32_t)g, m | (p.clamp ? 16 : 0));
       }
   }
   __syncthreads();
@@ -245,7 +247,12 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     if (TIGHT)
       for (int k = r; k < h; ++k)
         if ((int64_t)base[b] + k < capacity) keys[(int64_t)base[b] + k] = BK_SENTINEL;
-    if (r > 0) atomicAdd(&real_counts[b], r);
+    // pairs actually WRITTEN: in a frame that outgrows `capacity` (its lists are discarded and
+    // rebuilt) the count must still match what the sort pass finds in the buffer, or the compacted
+    // lists would have gaps of uninitialised pair words that the compositing kernels then follow
+    const int64_t room = capacity - (int64_t)base[b];
+    const int written = (int)(room <= 0 ? 0 : (room < r ? room : r));
+    if (written > 0) atomicAdd(&real_counts[b], written);
   }
 }
 
@@ -482,7 +489,7 @@ extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_
     gsr::set_error("bucket_count: %d buckets exceed the LDS histogram (%d)", nb, gsr::BK_MAX_BUCKETS);
     return GSR_ECAPACITY;
   }
-  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_count: C*N must be < 2^26 (composite key)");
+  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_count: C*N must be < 2^25 (composite key)");
   if (nb > 0 && !assume_zero)
     GSR_CHECK_HIP(hipMemsetAsync(bucket_counts, 0, sizeof(int32_t) * nb, (hipStream_t)stream));
   const int64_t total = (int64_t)C * N;
@@ -517,7 +524,7 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
     gsr::set_error("bucket_emit: %d buckets exceed the LDS histogram", nb);
     return GSR_ECAPACITY;
   }
-  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_emit: C*N must be < 2^26 (composite key)");
+  GSR_REQUIRE((int64_t)C * N < (1LL << gsr::BK_G_BITS), "bucket_emit: C*N must be < 2^25 (composite key)");
   const int64_t total = (int64_t)C * N;
   if (nb == 0) return GSR_OK;
   GSR_REQUIRE(bucket_counts && bucket_cursor && real_counts && bucket_offsets && (keys || capacity == 0),
@@ -585,7 +592,8 @@ pair_masks_kernel(int C, int N, int tile_w, int tile_h, const int32_t *__restric
   for (int i = s + (int)threadIdx.x; i < e; i += 256) {
     const uint32_t g = (uint32_t)flatten_ids[i];
     const PairGauss p = load_pair_gauss(means2d, conics, opacities, opac_per_camera, (int64_t)g, N, C);
-    pair_ids[i] = (int32_t)(g | ((uint32_t)pair_mask_of(p, tx, ty) << PAIR_MASK_SHIFT));
+    pair_ids[i] = (int32_t)(g | ((uint32_t)pair_mask_of(p, tx, ty) << PAIR_MASK_SHIFT) |
+                            (p.clamp ? PAIR_CLAMP_BIT : 0u));
   }
 }
 }  // namespace gsr
@@ -595,7 +603,7 @@ extern "C" int gsr_pair_masks(int C, int N, int tile_w, int tile_h, const int32_
                               const float *opacities, int opac_per_camera, int32_t *pair_ids,
                               void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0, "pair_masks: bad sizes");
-  GSR_REQUIRE((int64_t)C * N <= (int64_t)gsr::PAIR_ID_MASK, "pair_masks: C*N must be < 2^28 (pair word)");
+  GSR_REQUIRE((int64_t)C * N <= (int64_t)gsr::PAIR_ID_MASK, "pair_masks: C*N must be < 2^27 (pair word)");
   const int n_tiles = C * tile_w * tile_h;
   if (n_tiles == 0 || (int64_t)C * N == 0) return GSR_OK;
   GSR_REQUIRE(tile_offsets && flatten_ids && means2d && conics && opacities && pair_ids,

@@ -13,7 +13,8 @@
 // Round 3: the mask is computed ONCE per pair, where the pair is created (the emit pass
 // of isect_bucket.hip, or gsr_pair_masks for lists built elsewhere), and travels in the
 // top four bits of the pair word the compositing kernels read:
-//     pair_ids[i] = g | mask << 28          (g = camera * N + Gaussian < 2^28)
+//     pair_ids[i] = g | clamp << 27 | mask << 28     (g = camera * N + Gaussian < 2^27;
+//                                                    clamp = opacity > 0.999: alpha may reach its cap)
 // Before, both compositing kernels re-derived it while staging each batch (four
 // min_sigma_rect evaluations per pair and kernel, ~14 live registers that pushed the
 // forward into scratch and made it wait for its own prefetch: profiles/r03_fwd_timeline_before.json).
@@ -29,7 +30,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PIX_DONE = 1.0e18f;   // pixel x of a finished / outside pixel: sigma -> huge, alpha -> 0
 
 constexpr int PAIR_MASK_SHIFT = 28;
-constexpr uint32_t PAIR_ID_MASK = 0x0fffffffu;
+constexpr uint32_t PAIR_CLAMP_BIT = 1u << 27;   // opacity > 0.999: alpha can reach the clamp
+constexpr uint32_t PAIR_ID_MASK = 0x07ffffffu;
 
 // sigma' = log2(e) * sigma = ha*dx^2 + bb*dx*dy + hc*dy^2, evaluated identically in
 // forward and backward as dx*(ha*dx + B) + C with the row terms B = bb*dy, C = hc*dy*dy:
@@ -64,6 +66,7 @@ __device__ __forceinline__ float alpha_tau(float op) {
 // constants are set up once (PairConic), the x- and y-halves of the tile share their edge terms.
 struct PairConic {
   float mx, my, ha, hc, sx, sy, kx, ky, tau_m;   // ha = a/2, hc = c/2, sx = -b/a, sy = -b/c
+  bool clamp;                                    // opacity > 0.999 (gs::ALPHA_MAX)
 };
 __device__ __forceinline__ PairConic make_pair_conic(float mx, float my, float a, float b, float c,
                                                      float op) {
@@ -78,6 +81,7 @@ __device__ __forceinline__ PairConic make_pair_conic(float mx, float my, float a
   p.kx = 0.5f * (a - b * b * ic);
   p.ky = 0.5f * (c - b * b * ia);
   p.tau_m = alpha_tau(op);
+  p.clamp = op > gs::ALPHA_MAX;
   return p;
 }
 __device__ __forceinline__ int pair_quadrant_mask(const PairConic &p, float tx0, float ty0) {
@@ -200,6 +204,20 @@ __device__ __forceinline__ void dma_stage_batch(const float *__restrict__ record
   for (int h = 0; h < 2; ++h) {
     const uint32_t id = slot[16 * h + (lane >> 2)] & PAIR_ID_MASK;
     dma_16B(records + (int64_t)id * REC_FLOATS + 4 * (lane & 3), &dst[16 * h][0]);
+  }
+}
+
+// The same 32 records as three planes of 16-byte chunks, dst[c][r] = chunk c of record r (48 bytes
+// per record instead of a whole 64-byte row: the backward needs the LDS for a seventh wave per
+// SIMD). One DMA instruction per plane, lanes 0..31 active.
+__device__ __forceinline__ void dma_stage_batch_planes(const float *__restrict__ records, const uint32_t *slot,
+                                                       int lane_, float4 (*dst)[RBATCH]) {
+  const int lane = opaque(lane_);
+  if (lane < RBATCH) {
+    const uint32_t id = slot[lane] & PAIR_ID_MASK;
+    const float *src = records + (int64_t)id * REC_FLOATS;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dma_16B(src + 4 * c, &dst[c][0]);
   }
 }
 

@@ -276,21 +276,23 @@ l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ 
   double acc = wave_sum_f64((double)part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  // ws[0] = running sum, ws[1] = workgroups done (both zero on entry). The last workgroup
-  // writes the mean and leaves the workspace zero again: no memset launch before, no
-  // elementwise launches after. No fence: device-scope float atomics execute at the memory
-  // side, and the data dependence (the ticket increment carries the returned old sum) orders
-  // a workgroup's two atomics; a fence here would write back the XCD's whole L2.
+  // one partial per workgroup; l1_finalize_kernel (next launch: the boundary makes the partials
+  // visible) sums them. Until round 3 the workgroups added into ONE fp64 word and took a ticket
+  // from another: 1024 same-address atomics that serialise at the memory side (~12 ns each, half of
+  // the kernel's 27 us).
+  if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(512)
+l1_finalize_kernel(int n_partials, const double *__restrict__ ws, double inv_n, float *__restrict__ mean_out) {
+  __shared__ double red[8];
+  double acc = (int)threadIdx.x < n_partials ? ws[threadIdx.x] : 0.0;
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const double prev = atomicAdd(&ws[0], red[0] + red[1] + red[2] + red[3]);
-    const double one = (prev == prev) ? 1.0 : 1.0 + prev;          // depends on prev, always 1
-    const double done = atomicAdd(&ws[1], one);
-    if (done == (double)(gridDim.x - 1)) {
-      const double total = atomicAdd(&ws[0], 0.0);
-      mean_out[0] = (float)(total / (double)n);
-      __hip_atomic_store(&ws[0], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&ws[1], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    double t = 0.0;
+    for (int w = 0; w < 8; ++w) t += red[w];
+    mean_out[0] = (float)(t * inv_n);
   }
 }
 __global__ void __launch_bounds__(256)
@@ -318,10 +320,13 @@ extern "C" int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *wor
   GSR_REQUIRE(n > 0 && a && b && workspace && mean_out, "l1_fwd: bad arguments");
   GSR_REQUIRE(((uintptr_t)a | (uintptr_t)b | (uintptr_t)unit_grad) % 16 == 0,
               "l1_fwd: buffers must be 16-byte aligned");
-  int blocks = (int)(gsr::ceil_div64(n, 4096) < 512 ? gsr::ceil_div64(n, 4096) : 512);
+  int blocks = (int)(gsr::ceil_div64(n, 4096) < GSR_L1_WS_DOUBLES ? gsr::ceil_div64(n, 4096) : GSR_L1_WS_DOUBLES);
   hipLaunchKernelGGL(gsr::l1_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, a, b,
                      workspace, mean_out, unit_grad, (float)(1.0 / (double)n));
   GSR_CHECK_LAUNCH("l1_fwd");
+  hipLaunchKernelGGL(gsr::l1_finalize_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, blocks,
+                     workspace, 1.0 / (double)n, mean_out);
+  GSR_CHECK_LAUNCH("l1_finalize");
   return GSR_OK;
 }
 

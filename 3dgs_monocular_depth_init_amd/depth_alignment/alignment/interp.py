@@ -1,17 +1,23 @@
 """Scale-map interpolation alignment (tail).
 
-Mirror of /root/reference/gs_init_compare/depth_alignment/alignment/interp.py:
+Counterpart of /root/reference/gs_init_compare/depth_alignment/alignment/interp.py:
   linear_interpolation            77-110
   scale_factor_outlier_removal    161-201
   initial_alignment               204-235
   align_depth_interpolate         281-361, DepthAlignmentInterpolate 364-380
-The per-image pre-alignment is this build's RANSAC / LSQ (HIP). What the reference does on a few
-thousand SfM points with CPU libraries stays exactly that -- scikit-learn's LocalOutlierFactor /
-NearestNeighbors and scipy's Delaunay on the host (their neighbour tie-breaking and
-triangulation are part of the reference's results) -- while the expensive part, evaluating the
-piecewise-linear scale map at every pixel (LinearNDInterpolator on ~2 M queries on the CPU in
-the reference), runs as one HIP launch per image (`gsr_tri_interp`). method="rbf" needs torchrbf
-(absent) and is not built.
+Everything per point runs on the device with this repository's own kernels: the position-outlier
+test is `knn.local_outlier_factor` (gsr_knn_grid_idx + gsr_lof, the kernels pinned against
+scikit-learn by tests/test_lof_golden.py), the scale-outlier test takes the 5 nearest other points
+from `knn.knn_neighbors`, the per-image pre-alignment is the RANSAC / LSQ of this build, and the
+piecewise-linear scale map is evaluated at every pixel by one launch (`gsr_tri_interp`; the
+reference runs scipy's LinearNDInterpolator over ~2 M pixels on the CPU). The one host library
+left is scipy's Delaunay triangulation of the few thousand SfM pixels (the triangulation IS the
+reference's result; Qhull is what both use). scikit-learn is not imported here.
+Neighbour ties: SfM pixels are integers, so several points can sit at exactly the distance of the
+K-th neighbour; which of them scikit-learn's KD-tree reports is an accident of its traversal. The
+kernels here break ties by point index. A classification can differ from the reference's only for
+a point with such a tie (tests/test_interp_golden.py checks exactly that).
+method="rbf" needs torchrbf (absent) and is not built.
 """
 from __future__ import annotations
 
@@ -37,58 +43,71 @@ class OutlierClassification(NamedTuple):
     regular: torch.Tensor
 
 
+N_POSITION_NEIGHBOURS = 10     # local outlier factor of the pixel positions (interp.py:170)
+N_SCALE_NEIGHBOURS = 5         # a point's scale is compared with the median over this many neighbours
+
+
+def _on_device(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_cuda else t.cuda()
+
+
 def scale_factor_outlier_removal(coords: torch.Tensor, scales: torch.Tensor, debug_export_dir=None):
-    """interp.py:161-201. coords [M,2] pixel coordinates, scales [M] (any device)."""
-    from sklearn.neighbors import LocalOutlierFactor, NearestNeighbors
-    K_lof, K_scale_knn = 10, 5
-    num_pts = coords.shape[0]
-    if num_pts < min(K_lof + 1, K_scale_knn + 1):
-        z = torch.zeros(num_pts, dtype=torch.bool)
-        return OutlierClassification(z, z.clone(), z.clone(), torch.ones(num_pts, dtype=torch.bool))
-    coords_np = coords.cpu().numpy()
-    position_outliers_np = LocalOutlierFactor(n_neighbors=K_lof, n_jobs=-1).fit_predict(coords_np) == -1
-    model = NearestNeighbors(n_neighbors=K_scale_knn + 1, metric="euclidean").fit(coords_np)
-    _, knn_indices = model.kneighbors(coords_np)
-    knn_indices = torch.from_numpy(knn_indices[:, 1:]).to(scales.device)
-    knn_median_scale = torch.median(scales[knn_indices], dim=1).values
-    scale_diff = torch.abs(scales - knn_median_scale)
-    scale_outliers = scale_diff > torch.quantile(scale_diff, 0.99)
-    position_outliers = torch.from_numpy(position_outliers_np).to(scale_outliers.device)
+    """interp.py:161-201. coords [M,2] pixel coordinates, scales [M]; masks come back on the
+    device of `scales`. Position outliers: local outlier factor (10 neighbours, threshold -1.5);
+    scale outliers: |scale - median scale of the 5 nearest other points| above its own 0.99
+    quantile. Fewer than 6 points: nothing is an outlier."""
+    from ... import knn
+    M = coords.shape[0]
+    out_dev = scales.device
+    if M < min(N_POSITION_NEIGHBOURS, N_SCALE_NEIGHBOURS) + 1:
+        none = torch.zeros(M, dtype=torch.bool, device=out_dev)
+        return OutlierClassification(none, none.clone(), none.clone(), ~none)
+    xy = _on_device(coords).float()
+    pts = torch.cat([xy, torch.zeros(M, 1, device=xy.device)], dim=1).contiguous()   # the kNN kernels are 3-D
+    sc = _on_device(scales)
+    position_out, _ = knn.local_outlier_factor(pts, N_POSITION_NEIGHBOURS)
+    _, nb = knn.knn_neighbors(pts, N_SCALE_NEIGHBOURS)
+    deviation = (sc - sc[nb.long()].median(dim=1).values).abs()
+    scale_out = deviation > torch.quantile(deviation, 0.99)
     return OutlierClassification(
-        scale_only_outliers=scale_outliers & ~position_outliers,
-        both_outliers=scale_outliers & position_outliers,
-        position_only_outliers=position_outliers & ~scale_outliers,
-        regular=~(scale_outliers | position_outliers))
+        scale_only_outliers=(scale_out & ~position_out).to(out_dev),
+        both_outliers=(scale_out & position_out).to(out_dev),
+        position_only_outliers=(position_out & ~scale_out).to(out_dev),
+        regular=(~(scale_out | position_out)).to(out_dev))
+
+
+def _corner_values(simplices: np.ndarray, xy: np.ndarray, values: np.ndarray, n_pts: int) -> np.ndarray:
+    """Values of the four appended image corners (vertex ids n_pts .. n_pts+3): the mean of the
+    corner's triangulation neighbours among the real points, weighted by inverse distance
+    (interp.py:92-103). A corner's neighbours are the other vertices of the triangles it belongs to."""
+    out = np.empty(4, dtype=values.dtype)
+    for k in range(4):
+        c = n_pts + k
+        ring = np.unique(simplices[(simplices == c).any(axis=1)])
+        ring = ring[ring < n_pts]                                   # real points only, ascending
+        w = 1.0 / (np.hypot(*(xy[ring] - xy[c]).T) + 1e-8)
+        v = np.sum(values[ring] * (w / np.sum(w)))
+        out[k] = v if not np.isnan(v) else np.median(values[ring])
+    return out
 
 
 def linear_interpolation(coords: torch.Tensor, values: torch.Tensor, config, device, W: int, H: int) -> torch.Tensor:
-    """interp.py:77-110: Delaunay over the SfM pixels + the four image corners (corner values =
-    inverse-distance mean of their non-corner neighbours), piecewise-linear on every pixel.
-    Returns [H,W] on the device of `values`."""
+    """interp.py:77-110: Delaunay over the SfM pixels + the four image corners, piecewise-linear
+    on every pixel (pixels outside the hull: the median value). Returns [H,W] on the device of
+    `values` (or `device` for CPU input)."""
     from scipy.spatial import Delaunay
-    coords_np = coords.T.cpu().numpy()
-    values_np = values.cpu().numpy()
-    corner_coords = np.array([[0, 0], [0, H - 1], [W - 1, 0], [W - 1, H - 1]])
-    corner_indices = np.arange(coords_np.shape[0], coords_np.shape[0] + 4)
-    coords_np = np.vstack((coords_np, corner_coords))
-    values_np = np.hstack((values_np, np.empty(4, dtype=values_np.dtype)))
-    dt = Delaunay(coords_np)
-    for corner_ix in corner_indices:
-        indptr, indices = dt.vertex_neighbor_vertices
-        neighbors = np.setdiff1d(indices[indptr[corner_ix]: indptr[corner_ix + 1]], corner_indices)
-        distances = np.linalg.norm(coords_np[neighbors] - coords_np[corner_ix], axis=1)
-        weights = 1.0 / (distances + 1e-8)
-        weights /= np.sum(weights)
-        corner_value = np.sum(values_np[neighbors] * weights)
-        if np.isnan(corner_value):
-            corner_value = np.median(values_np[neighbors])
-        values_np[corner_ix] = corner_value
+    n_pts = coords.shape[1]
+    corners = np.array([[0, 0], [0, H - 1], [W - 1, 0], [W - 1, H - 1]], dtype=np.float64)
+    xy = np.concatenate([coords.T.cpu().numpy().astype(np.float64), corners])
+    vals = values.cpu().numpy()
+    tri = Delaunay(xy)
+    vals = np.concatenate([vals, _corner_values(tri.simplices, xy, vals, n_pts)])
     dev = values.device if values.is_cuda else torch.device(device)
-    out = torch.full((H, W), float(np.median(values_np)), dtype=torch.float32, device=dev)     # fill_value
-    xy = torch.from_numpy(np.ascontiguousarray(dt.points, dtype=np.float64)).to(dev)
-    tris = torch.from_numpy(np.ascontiguousarray(dt.simplices, dtype=np.int32)).to(dev)
-    vals = torch.from_numpy(values_np.astype(np.float64)).to(dev)
-    call("gsr_tri_interp", H, W, tris.shape[0], ptr(xy), ptr(tris), ptr(vals), ptr(out),
+    out = torch.full((H, W), float(np.median(vals)), dtype=torch.float32, device=dev)
+    xy_d = torch.from_numpy(np.ascontiguousarray(tri.points, dtype=np.float64)).to(dev)
+    tri_d = torch.from_numpy(np.ascontiguousarray(tri.simplices, dtype=np.int32)).to(dev)
+    val_d = torch.from_numpy(vals.astype(np.float64)).to(dev)
+    call("gsr_tri_interp", H, W, tri_d.shape[0], ptr(xy_d), ptr(tri_d), ptr(val_d), ptr(out),
          torch.cuda.current_stream().cuda_stream)
     return out.to(values.dtype)
 

@@ -169,6 +169,7 @@ class GatherRowsSync:
         set_row_exchange(self)
         self._views = None
         self._bufs = {}
+        self._bufs_n = -1
 
     def set_views(self, camtoworlds_all, Ks_all) -> None:
         from .rendering import inverse4x4
@@ -200,30 +201,38 @@ class GatherRowsSync:
         dev = rows.device
         W = self.world
         st = torch.cuda.current_stream().cuda_stream
-        nccl = W > 1 and dist.get_backend(self.group) == "nccl"
         chunks = []
+        if self._bufs_n != N:                   # the Gaussian count changed (densification): the old
+            self._bufs.clear()                  # generation's buffers (W*N*36 bytes in all) are dropped
+            self._bufs_n = N                    # before the chunk loop, never in the middle of a step
         for a, b in self.chunk_bounds(N):
             n = b - a
             key = (a, n)
             buf = self._bufs.get(key)
             if buf is None:
-                if len(self._bufs) > 64:
-                    self._bufs.clear()          # the Gaussian count changed (densification)
                 buf = self._bufs[key] = (torch.empty(W * n, 5, dtype=torch.int32, device=dev) if self.rows == "fp16"
                                          else torch.empty(W * n, 9, dtype=torch.float32, device=dev))
             mine = buf[self.rank * n:(self.rank + 1) * n]
             call("gsr_pack_grad_rows_h" if self.rows == "fp16" else "gsr_pack_grad_rows", n,
                  rows.data_ptr() + 64 * a, radii.data_ptr() + 8 * a, ptr(mine), st)
-            work = None
-            if nccl:
-                work = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)   # in place
-            elif W > 1:     # gloo (tests): list form, input must not alias the outputs
-                outs = [buf[r * n:(r + 1) * n] for r in range(W)]
-                work = dist.all_gather(outs, mine.clone(), group=self.group, async_op=True)
-            chunks.append((a, n, buf, (work.wait if work is not None else (lambda: None))))
+            chunks.append((a, n, buf, self._all_gather(buf, mine, a, n)))
         vm, Ks, campos = self._views
         self._views = None
         return chunks, vm, Ks, campos, W
+
+    def _all_gather(self, buf, mine, start: int, n: int):
+        """Start the exchange of one Gaussian range: `mine` (= buf[rank*n:(rank+1)*n], this rank's
+        packed rows) to every rank, segment r of `buf` <- rank r's rows. Returns the function that
+        waits for it. (Its own method so that tests can stand in for the other ranks of a large
+        world on one GPU: tests/test_gpu_two_ranks.py::test_world8_chunked_exchange...)"""
+        W = self.world
+        if W == 1:
+            return lambda: None
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True).wait   # in place
+        # gloo (tests): list form, input must not alias the outputs
+        outs = [buf[r * n:(r + 1) * n] for r in range(W)]
+        return dist.all_gather(outs, mine.clone(), group=self.group, async_op=True).wait
 
     def __call__(self) -> None:          # train_step's grad_sync hook: nothing left to do
         return None

@@ -98,15 +98,15 @@ def unit_gradient(device) -> Tensor:
 
 
 class _L1(torch.autograd.Function):
-    """mean |a - b| over contiguous buffers in ONE launch: the kernel finalises the mean
-    itself and writes sign(a-b)/n on the way; the backward returns that as is when the
+    """mean |a - b| over contiguous buffers: one streaming launch (per-workgroup partial sums, and
+    sign(a-b)/n written on the way) plus a one-workgroup launch that adds the partials; the backward returns that as is when the
     upstream gradient is the cached unit scalar, and scales it (one launch) otherwise."""
 
     @staticmethod
     def forward(ctx, a: Tensor, b: Tensor):
         ws = _L1_WS.get(a.device.index)
         if ws is None:
-            ws = _L1_WS[a.device.index] = torch.zeros(2, dtype=torch.float64, device=a.device)
+            ws = _L1_WS[a.device.index] = torch.empty(512, dtype=torch.float64, device=a.device)   # GSR_L1_WS_DOUBLES
         out = torch.empty((), dtype=torch.float32, device=a.device)
         grad = torch.empty_like(a) if a.requires_grad else None
         call("gsr_l1_fwd", a.numel(), ptr(a), ptr(b), ptr(ws), ptr(out), ptr(grad), _st())

@@ -53,16 +53,24 @@ def pick_model(config) -> Callable:
 
 def predict_depth_or_get_cached_depth(model: DepthPredictor, image: torch.Tensor,
                                       intrinsics: CameraIntrinsics, image_name: str, config,
-                                      dataset_name: str):
+                                      dataset_name: str, device=None):
     """monocular_depth_init.py:60-87; same directory layout and file name
     (`cache_dir/model.name/dataset/{image_name}.pth`). The payload is a weights-only-safe
-    dict of the PredictedDepth fields (see io.save_predicted_depth), not a pickled object."""
+    dict of the PredictedDepth fields (see io.save_predicted_depth), not a pickled object.
+
+    A cache hit is loaded onto `device` (an extra argument; default: the predictor's own
+    device, else the image's). The reference's `torch.load` restores the tensors to the cuda
+    device they were predicted on, whereas the dataset hands over CPU images
+    (datasets/colmap.py:384): loading onto `image.device` would return a CPU depth on every
+    second run and trip the caller's device assertion (monocular_depth_init.py:140)."""
+    if device is None:
+        device = getattr(model, "device", None) or image.device
     cache_path = gs_io.depth_cache_path(config.mdi.cache_dir, model.name, dataset_name, image_name)
     cache_path.parent.mkdir(exist_ok=True, parents=True)
     depth = None
     if not config.mdi.ignore_cache and cache_path.exists():
         try:
-            depth = gs_io.load_predicted_depth(cache_path, device=image.device)
+            depth = gs_io.load_predicted_depth(cache_path, device=device)
         except Exception as e:  # noqa: BLE001  (reference: any failure -> recompute)
             _LOGGER.warning("Failed to load cached depth for image %s: %s", image_name, e)
     if depth is None:
@@ -118,7 +126,7 @@ def pts_and_rgb_from_monocular_depth(config, parser, device: str = "cuda", model
         intrinsics = CameraIntrinsics(image.K)
         if use_cache:
             predicted_depth = predict_depth_or_get_cached_depth(
-                model, image.data, intrinsics, image.name, config, dataset_name)
+                model, image.data, intrinsics, image.name, config, dataset_name, device=device)
         else:
             predicted_depth = model.predict_depth(image.data, intrinsics)
         assert predicted_depth.depth.device == torch.device(device)     # :140

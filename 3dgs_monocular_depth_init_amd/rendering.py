@@ -425,9 +425,9 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
 
 
 def bucket_layout_ok(C: int, N: int, tile_w: int, tile_h: int) -> bool:
-    """The bucketed tile-list builder needs <= 8192 buckets (LDS histogram) and C*N < 2^26
-    (26 bits of the composite key hold the pair id, 4 its quadrant mask)."""
-    return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 26)
+    """The bucketed tile-list builder needs <= 8192 buckets (LDS histogram) and C*N < 2^25
+    (25 bits of the composite key hold the pair id, 5 its quadrant mask and clamp flag)."""
+    return C * tile_h * ((tile_w + 7) // 8) <= 8192 and C * N < (1 << 25)
 
 
 # Compositing work order: True (default) = longest TILE first, one more (single-workgroup, 8 us)

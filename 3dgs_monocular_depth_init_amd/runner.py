@@ -177,14 +177,17 @@ def train_step(
     from . import rendering as _R
     from .losses import unit_gradient
     fused = _R._BACKWARD_OPTIMIZER
-    if fused is not None and (opacity_reg > 0.0 or scale_reg > 0.0):
+    # reference order on the steps where the strategy edits parameters: backward -> strategy ->
+    # optimizer (runner.py:638-679); the fused update would land before the strategy
+    ordered = fused is not None and strategy is not None and strategy.mutates_params(step)
+    if fused is not None and not ordered and (opacity_reg > 0.0 or scale_reg > 0.0):
+        # (on `ordered` steps -- every step of MCMCStrategy, whose preset uses both regularisers --
+        # the fusion is suspended: the regularisers' gradients accumulate into .grad next to the
+        # rasterizer's, identically on all ranks, and the optimizer steps once, afterwards)
         raise RuntimeError(
             "train_step: opacity_reg / scale_reg reach the parameters outside the rasterizer; "
             "optimizer-in-backward (FusedAdam.fuse_into_backward, GatherRowsSync) would apply them "
             "in a second Adam step. Disable the fusion for this preset.")
-    # reference order on the steps where the strategy edits parameters: backward -> strategy ->
-    # optimizer (runner.py:638-679); the fused update would land before the strategy
-    ordered = fused is not None and strategy is not None and strategy.mutates_params(step)
     if ordered:
         _R.set_backward_optimizer(None)
     try:

@@ -339,13 +339,14 @@ int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1, const int64_
                     const float *upstream, float scale_ssim, float scale_l1, float *grad,
                     const int64_t *stridesg, void *stream);
 
-/* Plain L1 over n contiguous floats (16-byte aligned), ONE launch each way:
- * gsr_l1_fwd: mean_out[0] (device float) = mean |a-b|. workspace = 2 device doubles that are
- *   zero on entry and left zero on exit (allocate and zero once, reuse every step).
+/* Plain L1 over n contiguous floats (16-byte aligned) (replaces F.l1_loss, runner.py:506):
+ * gsr_l1_fwd: mean_out[0] (device float) = mean |a-b|. workspace = GSR_L1_WS_DOUBLES device
+ *   doubles, any content (one partial sum per workgroup; a second, one-workgroup launch adds them).
  *   unit_grad (NULL or n floats) receives sign(a-b)/n, the gradient w.r.t. a under an upstream
  *   gradient of 1: the backward is then free unless the loss is scaled further.
  * gsr_l1_bwd: grad = (upstream ? upstream[0] : 1) * scale * sign(a-b); upstream is the device
  *   scalar autograd hands the loss, scale = 1/n. */
+#define GSR_L1_WS_DOUBLES 512
 int gsr_l1_fwd(int64_t n, const float *a, const float *b, double *workspace, float *mean_out,
                float *unit_grad, void *stream);
 int gsr_l1_bwd(int64_t n, const float *a, const float *b, const float *upstream, float scale,

@@ -111,3 +111,48 @@ with torch.no_grad():
         print(k, out[k].shape, float(np.abs(out[k].astype(np.float32)).mean()), float(np.abs(out[k].astype(np.float32)).max()))
 np.savez_compressed(HERE / "depthnet_golden.npz", **out)
 print("wrote depthnet_golden.npz")
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 3: the two networks the reference actually loads (predictors/metric3d.py:20-25), at their
+# FULL depth, width and iteration count -- vit_small_reg (:1211) / vit_large_reg (:1227) with the
+# decoder configurations of dino_vit_{small,large}_reg.dpt_raft.py -- on the small 112x168 input
+# (101 tokens), which the CPU affords: 12 / 24 residual blocks and 4 / 8 ConvGRU iterations are
+# where fp16 drift would accumulate. Written to a second file (depthnet_full_golden.npz).
+# ---------------------------------------------------------------------------------------------
+FULL = {
+    "vits": dict(embed_dim=384, depth=12, heads=6, feature_channels=[96, 192, 384, 768],
+                 decoder_channels=[48, 96, 192, 384, 384], hidden=[48, 48, 48, 48], iters=4),
+    "vitl": dict(embed_dim=1024, depth=24, heads=16, feature_channels=[256, 512, 1024, 1024],
+                 decoder_channels=[128, 256, 512, 1024, 1024], hidden=[128, 128, 128, 128], iters=8),
+}
+full = {}
+with torch.no_grad():
+    for name, c in FULL.items():
+        enc = vit(c["embed_dim"], c["heads"], c["depth"])
+        feats, meta = enc(img)
+        full[f"{name}_tokens"] = feats[0][0].numpy().astype(np.float16)
+        cfg = NS(model=NS(decode_head=NS(in_channels=[c["embed_dim"]] * 4, use_cls_token=True,
+                                         feature_channels=c["feature_channels"], decoder_channels=c["decoder_channels"],
+                                         up_scale=7, hidden_channels=c["hidden"], n_gru_layers=3, n_downsample=2,
+                                         iters=c["iters"], slow_fast_gru=True, num_register_tokens=4)),
+                 data_basic=NS(depth_normalize=(0.1, 200)))
+        dec = D.RAFTDepthNormalDPT5(cfg).eval()
+        dec.load_state_dict(DW.fill(dec))
+        dec.register_buffer("depth_expectation_anchor", bins, persistent=False)
+        deltas = []
+        hook = dec.update_block.register_forward_hook(
+            lambda m, i, o: deltas.append(o[2][0].permute(1, 2, 0).numpy()) if isinstance(o, tuple) and len(o) == 3 else None)
+        o = dec([feats, meta])
+        hook.remove()
+        assert len(deltas) == c["iters"]
+        full[f"{name}_delta_last"] = deltas[-1]
+        full[f"{name}_depth"] = o["prediction"][0, 0].numpy()
+        full[f"{name}_conf"] = o["confidence"][0, 0].numpy()
+        full[f"{name}_normal"] = o["prediction_normal"][0].numpy()
+        for k in ("tokens", "depth", "conf", "normal", "delta_last"):
+            a = full[f"{name}_{k}"].astype(np.float32)
+            print(name, k, a.shape, float(np.abs(a).mean()), float(np.abs(a).max()))
+        del enc, dec
+np.savez_compressed(HERE / "depthnet_full_golden.npz", **full)
+print("wrote depthnet_full_golden.npz")

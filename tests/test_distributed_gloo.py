@@ -131,3 +131,76 @@ def test_chunk_to_parameter_pieces_cover_every_element_once():
                 assert start % 4 == 0 and cnt > 0
                 seen[k][start:start + cnt] += 1
         assert all(bool((v == 1).all()) for v in seen.values())
+
+
+def _worker8(rank, world, port, q):
+    """World size 8 (gloo, CPU): the host logic of the view-parallel step at the size the driver's
+    scaling run uses -- camera sharding incl. the wrap-around of bench.py's camera table, the
+    Gaussian-range chunking, and the segment layout of the row exchange (rank r's rows in
+    rows_all[r*n:(r+1)*n] on every rank, summed in rank order)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+        n_cams = 100
+        table = torch.arange(n_cams)
+        table_w = torch.cat([table, table[:world]])            # bench.py: c2ws_w = cat([c2ws, c2ws[:world]])
+        mine = []
+        for step in range(30):                                 # 240 views: the table wraps twice
+            a = (step * world) % n_cams
+            views = table_w[a:a + world]                       # the slice every rank hands to set_views
+            cam = D.shard_views(n_cams, step, rank, world)
+            assert int(views[rank]) == cam == (step * world + rank) % n_cams
+            assert views.numel() == world and len(set(views.tolist())) == world
+            mine.append(cam)
+        # chunking of the Gaussian range (no GPU needed: chunk_bounds is host arithmetic)
+        sync = object.__new__(D.GatherRowsSync)
+        sync.chunks, sync.min_chunk = 4, 4096
+        for N in (1_000_000, 999_999, 4096, 4097, 16385, 100, 64, 1):
+            cb = sync.chunk_bounds(N)
+            assert cb[0][0] == 0 and cb[-1][1] == N and len(cb) <= 4
+            assert all(b0 == a1 for (_, b0), (a1, _) in zip(cb[:-1], cb[1:]))
+            assert all(a % 64 == 0 for a, _ in cb) and all(b > a for a, b in cb)
+        # exchange layout: every rank contributes rows that encode (rank, Gaussian); after the
+        # all-gather the sum over segments in rank order is the same tensor on all ranks
+        N = 1000
+        for a, b in sync.chunk_bounds(N) if False else [(0, 448), (448, 1000)]:
+            n = b - a
+            buf = torch.zeros(world * n, 9)
+            seg = (torch.arange(a, b, dtype=torch.float32)[:, None] * 0.001 + rank + 1).expand(n, 9).contiguous()
+            outs = [buf[r * n:(r + 1) * n] for r in range(world)]
+            dist.all_gather(outs, seg)
+            for r in range(world):
+                assert torch.equal(buf[r * n:(r + 1) * n, 0], torch.arange(a, b, dtype=torch.float32) * 0.001 + r + 1)
+            total = torch.zeros(n, 9)
+            for r in range(world):
+                total += buf[r * n:(r + 1) * n]
+            ref = [torch.zeros_like(total) for _ in range(world)]
+            dist.all_gather(ref, total)
+            assert all(torch.equal(ref[0], x) for x in ref)
+        q.put((rank, mine, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_view_sharding_chunking_and_exchange_layout():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort()
+    assert all(r[2] == "ok" for r in res), [r[2] for r in res if r[2] != "ok"][:1]
+    # per step the eight ranks cover eight distinct consecutive cameras (mod 100)
+    for step in range(30):
+        cams = [res[r][1][step] for r in range(world)]
+        assert cams == [(step * world + r) % 100 for r in range(world)]

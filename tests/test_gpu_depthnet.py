@@ -169,7 +169,11 @@ def test_layernorm_conv_resize_pool_vs_torch(N):
     assert torch.allclose(out.t.float().cpu().view(*ref.shape), ref, rtol=2e-3, atol=2e-3)
 
 
-def _close(got, ref, max_frac=2e-2, mean_frac=4e-3, what=""):
+def _close(got, ref, max_frac=3e-3, mean_frac=3e-3, what=""):
+    """|got - ref| <= max_frac * max|ref| everywhere and mean|got - ref| <= mean_frac * mean|ref|.
+    Defaults = 3x the errors round 2 recorded for these fixtures (profiles/parity_r02.json: 4e-4 ..
+    1e-3 of the maximum, ~5e-4 .. 1e-3 of the mean): fp16 storage of activations and weights against
+    the reference's fp32 modules."""
     got, ref = got.float().cpu(), torch.as_tensor(np.asarray(ref, dtype=np.float32))
     err = (got - ref).abs()
     from tests import parity_log
@@ -278,14 +282,15 @@ def test_decoder_vs_reference_golden(N):
     _close(inter["depth_init"].view(rf.H, rf.W, 6), G["dec_depth_init"], what="depth_init")
     for i in range(3):
         m, c = inter["nets"][i], inter["ctxs"][i]
-        _close(m.t[:, :m.C].reshape(m.H, m.W, m.C), G[f"dec_net{i}"].astype(np.float32), what=f"net{i}")
+        # (tanh outputs in [-1, 1]: the largest error, 4.2e-3, is an fp16 ulp pair near saturation)
+        _close(m.t[:, :m.C].reshape(m.H, m.W, m.C), G[f"dec_net{i}"].astype(np.float32), max_frac=1.3e-2, what=f"net{i}")
         _close(c.t[:, :c.C].reshape(c.H, c.W, c.C), G[f"dec_ctx{i}"].astype(np.float32), what=f"ctx{i}")
     for i, dl in enumerate(inter["deltas"]):
-        _close(dl.view(rf.H, rf.W, 6), G[f"dec_delta{i}"], max_frac=4e-2, mean_frac=2e-2, what=f"delta_flow{i}")
+        _close(dl.view(rf.H, rf.W, 6), G[f"dec_delta{i}"], max_frac=5e-3, mean_frac=5e-3, what=f"delta_flow{i}")
     assert depth.shape == (1, 1, 112, 168) and normal.shape == (1, 4, 112, 168)
-    _close(depth[0, 0], G["dec_depth"], what="depth")
-    _close(conf[0, 0], G["dec_conf"], max_frac=4e-2, mean_frac=1e-2, what="confidence")
-    _close(normal[0], G["dec_normal"], max_frac=4e-2, mean_frac=1e-2, what="normal")
+    _close(depth[0, 0], G["dec_depth"], max_frac=5e-3, what="depth")
+    _close(conf[0, 0], G["dec_conf"], max_frac=5e-3, mean_frac=5e-3, what="confidence")
+    _close(normal[0], G["dec_normal"], max_frac=6e-3, mean_frac=5e-3, what="normal")
 
 
 def test_end_to_end_small_and_predictor(N):
@@ -294,7 +299,7 @@ def test_end_to_end_small_and_predictor(N):
     ifc = mod("depth_prediction.predictors.depth_predictor_interface")
     net = N.Metric3DNet(_state(SMALL_CFG), device="cuda", input_size=(112, 168), config=SMALL_CFG)
     d, c, o = net.inference({"input": DW.image(112, 168)})       # eager pass + graph capture + replay
-    _close(d[0, 0], G["dec_depth"], max_frac=4e-2, mean_frac=1e-2, what="e2e depth")
+    _close(d[0, 0], G["dec_depth"], max_frac=5e-3, mean_frac=4e-3, what="e2e depth")
     assert torch.isfinite(o["prediction_normal"]).all()
     # graph replay on a second image == eager on that image
     img2 = DW.image(112, 168).flip(-1).contiguous()
@@ -312,6 +317,63 @@ def test_full_size_vits_runs(N):
     """c3's network at its real size: ViT-S/14-reg + RAFT-DPT at 616x1064 (3349 tokens)."""
     cfg = N.CONFIGS["vits"]
     net = N.Metric3DNet(_state(cfg), backbone="vits", device="cuda")
+    d, c, o = net.inference({"input": DW.image(616, 1064)})
+    torch.cuda.synchronize()
+    assert d.shape == (1, 1, 616, 1064) and o["prediction_normal"].shape == (1, 4, 616, 1064)
+    assert torch.isfinite(d).all() and torch.isfinite(c).all() and torch.isfinite(o["prediction_normal"]).all()
+    assert float(d.min()) >= 0.1 and float(d.max()) <= 200.0
+
+
+FG = np.load(Path(__file__).resolve().parent / "golden" / "depthnet_full_golden.npz")
+
+
+@pytest.mark.parametrize("name", ["vits", "vitl"])
+def test_full_depth_networks_vs_reference_golden(N, name):
+    """The two networks the reference loads (metric3d.py:20-25) at their FULL configuration --
+    vit_small_reg: 384-d, 6 heads, 12 blocks, 4 ConvGRU iterations; vit_large_reg: 1024-d, 16 heads,
+    24 blocks, 8 iterations; decoder channel plans of dino_vit_*_reg.dpt_raft.py -- against
+    activations recorded from the reference's vendored modules (tests/golden/make_depthnet_golden.py),
+    on the 112x168 input the CPU generator affords. 24 residual blocks and 8 recurrent refinements are
+    where fp16 drift would accumulate; the 2-block fixtures cannot show it."""
+    cfg = N.CONFIGS[name]
+    net = N.Metric3DNet(_state(cfg), backbone=name, device="cuda", input_size=(112, 168))
+    tokens = net.encode(DW.image(112, 168))
+    assert tokens.shape == (101, cfg["embed_dim"])
+    _close(tokens, FG[f"{name}_tokens"].astype(np.float32), max_frac=6e-3, mean_frac=4e-3, what=f"{name} tokens")
+    # the decoder on the REFERENCE encoder's tokens (so that the two halves are judged separately)
+    ref_tokens = torch.from_numpy(FG[f"{name}_tokens"]).half().cuda()
+    depth, conf, normal, inter = net.decode(ref_tokens, return_intermediates=True)
+    assert len(inter["deltas"]) == cfg["iters"]
+    _close(inter["deltas"][-1].view(28, 42, 6), FG[f"{name}_delta_last"], max_frac=1e-2, mean_frac=6e-3,
+           what=f"{name} delta_flow[{cfg['iters'] - 1}]")
+    _close(conf[0, 0], FG[f"{name}_conf"], max_frac=1e-2, mean_frac=6e-3, what=f"{name} confidence")
+    _close(normal[0], FG[f"{name}_normal"], max_frac=1e-2, mean_frac=6e-3, what=f"{name} normal")
+    # depth: with random weights the recurrent updates push most pixels into the [0.1, 200] clamp;
+    # compared where the reference is not saturated (and the saturated set must agree)
+    ref_d = torch.from_numpy(FG[f"{name}_depth"])
+    got_d = depth[0, 0].float().cpu()
+    free = ref_d < 199.0
+    assert float(((got_d >= 199.0) != ~free).float().mean()) <= 5e-3
+    if int(free.sum()) > 100:
+        rel = ((got_d - ref_d).abs() / ref_d)[free]
+        from tests import parity_log
+        p999 = float(torch.quantile(rel, 0.999))
+        parity_log.record("depthnet", what=f"{name} depth (unsaturated)", pixels=int(free.sum()),
+                          max_rel_err=float(rel.max()), p999_rel_err=p999, mean_rel_err=float(rel.mean()))
+        # (the final depth is an exponential of the accumulated updates, times a convex upsampling
+        # of a [0.1, 200]-clamped map: a pixel next to a saturated neighbour can move by tens of
+        # per cent when that neighbour crosses the clamp; hence a quantile, not the maximum)
+        assert float(rel.mean()) <= 5e-3 and p999 <= 5e-2
+    # and the whole chain, encoder into decoder
+    d2, c2, o2 = net.inference({"input": DW.image(112, 168)})
+    _close(c2[0, 0], FG[f"{name}_conf"], max_frac=2e-2, mean_frac=1e-2, what=f"{name} e2e confidence")
+
+
+def test_full_size_vitl_runs(N):
+    """c5's network at its real size: ViT-L/14-reg (24 blocks, 1024-d) + RAFT-DPT (8 iterations) at
+    616x1064 (3349 tokens)."""
+    cfg = N.CONFIGS["vitl"]
+    net = N.Metric3DNet(_state(cfg), backbone="vitl", device="cuda")
     d, c, o = net.inference({"input": DW.image(616, 1064)})
     torch.cuda.synchronize()
     assert d.shape == (1, 1, 616, 1064) and o["prediction_normal"].shape == (1, 4, 616, 1064)

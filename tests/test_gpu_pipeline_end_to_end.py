@@ -114,3 +114,87 @@ def test_depth_init_then_training():
         rc, _, _ = runner.rasterize_splats(splats, c2ws[:1], Ks[:1], W, H, sh_degree=3)
         mse = float(((rc.clamp(0, 1) - targets[0]) ** 2).mean())
     assert -10.0 * math.log10(mse) > 20.0, -10.0 * math.log10(mse)
+
+
+def test_reference_entry_point_cache_miss_then_hit(tmp_path):
+    """`pts_and_rgb_from_monocular_depth(config, parser, device)` -- the reference's own signature
+    (monocular_depth_init.py:95) -- against a duck-typed parser whose dataset yields CPU images, as
+    the reference's does (datasets/colmap.py:384), twice: the first run predicts and fills the depth
+    cache, the second one must hit it (the predictor refuses to be called again), load the depth
+    onto the compute device and return the same cloud."""
+    import numpy as np
+    from tests import scenes
+    MDI = importlib.import_module(P_ + "monocular_depth_init")
+    cfgm = importlib.import_module(P_ + "config")
+    dac = importlib.import_module(P_ + "depth_alignment.config")
+    ifc = importlib.import_module(P_ + "depth_prediction.predictors.depth_predictor_interface")
+    W, H, n_cam = 96, 64, 3
+    g = torch.Generator().manual_seed(5)
+    vms, Ks = scenes.cameras(range(0, 30, 10), width=W, height=H, f=90.0, dist=2.5)
+    c2ws = torch.linalg.inv(vms).contiguous()
+    # a tilted plane seen by every camera: depth per pixel in closed form is not needed, the "network"
+    # simply returns a smooth positive map and the SfM points are consistent with 2*d + 0.5
+    depth_maps = [1.0 + 0.3 * torch.rand(1, generator=g) + 0.2 * torch.linspace(0, 1, W)[None, :].expand(H, W)
+                  + 0.1 * torch.linspace(0, 1, H)[:, None].expand(H, W) for _ in range(n_cam)]
+    names = [f"img{i}.png" for i in range(n_cam)]
+    points, point_indices = [], {}
+    for i in range(n_cam):
+        ys = torch.randint(2, H - 2, (150,), generator=g)
+        xs = torch.randint(2, W - 2, (150,), generator=g)
+        z = 2.0 * depth_maps[i][ys, xs] + 0.5
+        Kc = Ks[i]
+        cam = torch.stack([(xs + 0.0 - Kc[0, 2]) / Kc[0, 0] * z, (ys + 0.0 - Kc[1, 2]) / Kc[1, 1] * z, z], 1)
+        world = cam @ c2ws[i][:3, :3].T + c2ws[i][:3, 3]
+        point_indices[names[i]] = np.arange(len(points) * 150, (len(points) + 1) * 150)
+        points.append(world)
+
+    class Dataset:                                   # what datasets/colmap.py:381-412 yields: CPU tensors
+        def __init__(self, parser, split="train"):
+            assert split == "train"
+
+        def __iter__(self):
+            for i in range(n_cam):
+                img = (torch.rand(H, W, 3, generator=torch.Generator().manual_seed(i)) * 255.0).float()
+                yield {"image": img, "image_name": names[i], "camtoworld": c2ws[i], "K": Ks[i], "image_id": i}
+
+    class Parser:
+        DatasetCls = Dataset
+        dataset_name = "synthetic_plane"
+        scene_scale = 1.0
+
+    parser = Parser()
+    parser.points = torch.cat(points).numpy()
+    parser.points_rgb = np.full((len(parser.points), 3), 128, dtype=np.uint8)
+    parser.point_indices = point_indices
+
+    class Net:
+        name = "fakenet"
+        device = torch.device("cuda:0")
+
+        def __init__(self):
+            self.calls, self.allowed = 0, True
+
+        def predict_depth(self, image, intrinsics):
+            assert self.allowed, "cache hit expected: the predictor must not run again"
+            d = depth_maps[self.calls % n_cam].to(self.device).contiguous()
+            self.calls += 1
+            return ifc.PredictedDepth(depth=d, mask=torch.ones_like(d, dtype=torch.bool))
+
+    cfg = cfgm.Config()
+    cfg.mdi.alignment.aligner = dac.DepthAlignmentStrategyEnum.lstsqrs
+    cfg.mdi.subsample_factor = 4
+    cfg.mdi.cache_dir = str(tmp_path / "depth_cache")
+    cfg.mdi.ignore_cache = False
+    net = Net()
+    out1 = MDI.pts_and_rgb_from_monocular_depth(cfg, parser, "cuda:0", model=net)
+    assert net.calls == n_cam
+    cached = sorted((tmp_path / "depth_cache").rglob("*.pth"))
+    assert len(cached) == n_cam
+    net.allowed = False
+    out2 = MDI.pts_and_rgb_from_monocular_depth(cfg, parser, "cuda:0", model=net)
+    for a, b in zip(out1, out2):
+        if a is None:
+            assert b is None
+            continue
+        assert a.device.type == "cuda" and torch.equal(a, b)
+    assert out1[0].shape[0] > 500

@@ -265,3 +265,102 @@ def test_two_ranks_replicas_stay_identical_through_densification():
     assert len(set(a["sizes"].tolist())) >= 3 and int(a["sizes"][-1]) != N, a["sizes"]
     for k in a:
         assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+
+
+# ------------------------------------------------------------------------------------------------- #
+# W = 8, functionally, on one GPU: one process plays the eight ranks in turn. GatherRowsSync's own
+# code runs unchanged (chunk_bounds, packing, the chunked gsr_project_bwd_adam(C = 8) loop of
+# rendering._ProjectSH.backward); only the collective is stood in for (`_all_gather`).
+# ------------------------------------------------------------------------------------------------- #
+def _world8_run(rows_mode):
+    """Returns (params after one 8-view step through the chunked exchange, as rank 0 computes
+    them; the same from rank 5's point of view)."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    WORLD, n8 = 8, 6000
+    sc = scenes.make_scene(n8, 2, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    vm, K = scenes.cameras(range(0, 96, 12), width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(WORLD, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def fresh():
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(n8, 3, generator=torch.Generator().manual_seed(0)),
+            torch.log(sc["scales"]), quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]),
+            shN=sc["shN"], batch_size=1, world_size=WORLD)
+        return splats, D.fuse_optimizers(splats, opts)
+
+    recorded = {}          # (rank, start, n) -> that rank's packed rows of the range
+
+    class OneOfEight(D.GatherRowsSync):
+        record_only = True
+
+        def _all_gather(self, buf, mine, start, n):
+            if self.record_only:
+                recorded[(self.rank, start, n)] = mine.clone()
+            for r in range(self.world):
+                # final pass: every segment -- this rank's own too -- is the row set recorded for that
+                # rank, as in a real exchange where a rank's rows exist once (recomputing them would
+                # differ in the last bits: the compositing atomics are order-nondeterministic)
+                if r != self.rank or not self.record_only:
+                    seg = recorded.get((r, start, n))
+                    buf[r * n:(r + 1) * n] = seg if seg is not None else 0   # recording pass: others unknown yet
+            return lambda: None
+
+    def one_rank_step(rank, record_only):
+        """Rank `rank`'s step. Recording pass: the gathered buffer is incomplete, so the update is
+        thrown away (fresh parameters every time) -- only this rank's packed rows are kept."""
+        splats, fused = fresh()
+        sync = OneOfEight(fused, WORLD, rank, chunks=4, min_chunk=512, rows=rows_mode)
+        sync.record_only = record_only
+        assert len(sync.chunk_bounds(n8)) == 4
+        try:
+            sync.set_views(c2w, K)
+            runner.train_step(splats, fused, c2w[rank:rank + 1], K[rank:rank + 1], target[rank:rank + 1],
+                              step=7000, grad_sync=sync)
+        finally:
+            sync.close()
+        torch.cuda.synchronize()
+        return {k: p.detach().clone() for k, p in splats.items()}
+
+    for r in range(WORLD):
+        one_rank_step(r, True)
+    assert len(recorded) == WORLD * 4
+    return one_rank_step(0, False), one_rank_step(5, False), (runner, D, fresh, c2w, K, target, n8)
+
+
+def test_world8_chunked_exchange_equals_eight_camera_batch():
+    """Eight views per step through GatherRowsSync's chunked exchange (4 Gaussian ranges, C = 8 in
+    gsr_project_bwd_adam) give (a) the same parameters on every rank (checked for ranks 0 and 5:
+    bit-identical, both sum the views in rank order), (b) the parameters one process gets from the
+    eight-camera batch (loss = sum of the per-view means) with the ordinary fused step."""
+    p0, p5, (runner, D, fresh, c2w, K, target, n8) = _world8_run("fp32")
+    for k in p0:
+        assert torch.equal(p0[k], p5[k]), f"ranks 0 and 5 disagree in {k}"
+    splats, fused = fresh()
+    renders, _, _ = runner.rasterize_splats(splats, c2w, K, W, H, sh_degree=3)      # C = 8 in one call
+    (renders - target).abs().mean(dim=(1, 2, 3)).sum().backward()
+    fused.step()
+    torch.cuda.synchronize()
+    for k in p0:
+        ref = splats[k].detach()
+        assert torch.allclose(p0[k], ref, rtol=1e-4, atol=1e-6), f"{k}: chunked W=8 exchange != 8-camera batch"
+        assert float((ref - fresh()[0][k].detach()).abs().max()) > 0, f"{k} did not move"
+
+
+def test_world8_half_rows_within_tolerance():
+    """The same with rows="fp16" (20-byte rows): ranks still bit-identical. Against the fp32 exchange:
+    the FIRST Adam step moves every element by about lr * sign(gradient), so an element whose
+    gradient is within half-precision rounding of zero can land on the other side (a difference of
+    twice the travel); all but a few per cent of the elements must agree to a quarter of the travel."""
+    h0, h5, _ = _world8_run("fp16")
+    f0, _, (runner, D, fresh, *_rest) = _world8_run("fp32")
+    init = {k: p.detach() for k, p in fresh()[0].items()}
+    for k in h0:
+        assert torch.equal(h0[k], h5[k]), f"ranks 0 and 5 disagree in {k}"
+        travel = float((f0[k] - init[k]).abs().max())
+        off = ((h0[k] - f0[k]).abs() > 0.25 * travel).float().mean()
+        assert float(off) <= 0.05, (k, float(off))
+        assert float((h0[k] - f0[k]).abs().max()) <= 2.0 * travel * (1 + 1e-3) + 1e-12, k

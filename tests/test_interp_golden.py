@@ -1,7 +1,7 @@
 """Scale-map interpolation aligner (SURVEY.md F4 tail) against outputs of the reference's own
-depth_alignment/alignment/interp.py (tests/golden/make_interp_golden.py).
-CPU part: the host-side outlier classification (scikit-learn, as in the reference) -- exact.
-GPU part: the per-pixel piecewise-linear scale map (`gsr_tri_interp`) and the whole
+depth_alignment/alignment/interp.py (tests/golden/make_interp_golden.py): the outlier
+classification (this build's kNN + LOF kernels against the reference's scikit-learn calls), the
+per-pixel piecewise-linear scale map (`gsr_tri_interp`) and the whole
 `DepthAlignmentInterpolate.align` chain."""
 import importlib
 from pathlib import Path
@@ -23,13 +23,48 @@ def _case(i):
                 init=None if init == "None" else init, removal=bool(int(removal)), rng_seed=int(rng_seed), H=H, W=W)
 
 
+def _tie_sensitive(coords_xy: np.ndarray, K: int) -> np.ndarray:
+    """Points whose K nearest OTHER points are not a unique set: the K-th and (K+1)-th neighbour lie
+    at exactly the same distance (integer pixels make that common). Which of the tied points a
+    neighbour search reports is an implementation accident (scikit-learn: KD-tree traversal order;
+    here: point index), so results may legitimately differ there -- and only there."""
+    d = np.hypot(coords_xy[:, None, 0] - coords_xy[None, :, 0], coords_xy[:, None, 1] - coords_xy[None, :, 1])
+    np.fill_diagonal(d, np.inf)
+    d.sort(axis=1)
+    return d[:, K - 1] == d[:, K]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("i", range(int(G["n"])))
 def test_outlier_classification_matches_reference(i):
     I = importlib.import_module(P_ + "depth_alignment.alignment.interp")
     c = _case(i)
-    oc = I.scale_factor_outlier_removal(c["coords"].T, torch.from_numpy(G[f"i{i}_scale_factors"]))
-    assert torch.equal(oc.scale_only_outliers, torch.from_numpy(G[f"i{i}_scale_only_outliers"]))
-    assert torch.equal(oc.position_only_outliers, torch.from_numpy(G[f"i{i}_position_only_outliers"]))
+    sf = torch.from_numpy(G[f"i{i}_scale_factors"])
+    oc = I.scale_factor_outlier_removal(c["coords"].T, sf)
+    assert oc.regular.device == sf.device
+    xy = c["coords"].T.numpy().astype(np.float64)
+    # scale outliers: a point's own 5-neighbour set, exact unless that set is tied
+    tie5 = torch.from_numpy(_tie_sensitive(xy, I.N_SCALE_NEIGHBOURS))
+    ref_so = torch.from_numpy(G[f"i{i}_scale_only_outliers"])
+    ref_po = torch.from_numpy(G[f"i{i}_position_only_outliers"])
+    # position outliers depend on the 10-neighbour sets of a point AND of its neighbours: tie-sensitive
+    # if any of those is tied
+    tie10 = _tie_sensitive(xy, I.N_POSITION_NEIGHBOURS)
+    d = np.hypot(xy[:, None, 0] - xy[None, :, 0], xy[:, None, 1] - xy[None, :, 1])
+    np.fill_diagonal(d, np.inf)
+    nb10 = np.argsort(d, axis=1, kind="stable")[:, :I.N_POSITION_NEIGHBOURS]
+    tie_lof = torch.from_numpy(tie10 | tie10[nb10].any(axis=1))
+    bad_so = (oc.scale_only_outliers != ref_so) & ~(tie5 | tie_lof)
+    bad_po = (oc.position_only_outliers != ref_po) & ~(tie5 | tie_lof)
+    assert int(bad_so.sum()) == 0 and int(bad_po.sum()) == 0, (int(bad_so.sum()), int(bad_po.sum()))
+    # and in total only a few points may differ at all (the 0.99 quantile itself can move when a
+    # tied median changes)
+    n = ref_so.numel()
+    assert int((oc.scale_only_outliers != ref_so).sum()) <= max(2, n // 100)
+    assert int((oc.position_only_outliers != ref_po).sum()) <= max(2, n // 50)
+    # the four classes partition the points
+    total = oc.scale_only_outliers.int() + oc.both_outliers.int() + oc.position_only_outliers.int() + oc.regular.int()
+    assert bool((total == 1).all())
 
 
 @pytest.mark.gpu
