@@ -87,11 +87,24 @@ bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
   __syncthreads();
   const int64_t total = (int64_t)C * N;
   const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
-  for (int64_t g = g0 + threadIdx.x; g < g1; g += BK_THREADS) {
-    int x0, x1, y0, y1;
-    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h,
-                    [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+  constexpr int UB = 4;   // four Gaussians per thread and trip, their loads issued together
+  for (int64_t gb = g0 + threadIdx.x; gb < g1; gb += UB * BK_THREADS) {
+    float2 m2[UB];
+    int2 rd[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
+      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
+      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = gb + (int64_t)u * BK_THREADS;
+      int x0, x1, y0, y1;
+      if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
+      for_each_bucket(C == 1 ? 0 : (int)(g / N),   /* 64-bit division only with several cameras */ x0, x1, y0, y1, bw, tile_h,
+                      [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+    }
   }
   __syncthreads();
   for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS)
@@ -210,11 +223,27 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   }
   const int64_t total = (int64_t)C * N;
   const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
-  for (int64_t g = g0 + tid; g < g1; g += BK_THREADS) {
-    int x0, x1, y0, y1;
-    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    for_each_bucket(C == 1 ? 0 : (int)(g / N), x0, x1, y0, y1, bw, tile_h,
-                    [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+  // Both passes over the workgroup's Gaussians take them FOUR per thread at a time, all loads of
+  // the four issued before the first is used (a thread walking its Gaussians one by one exposes a
+  // memory round trip per Gaussian and pass; measured: no gain on c4, kept for its shape).
+  constexpr int UB = 4;
+  for (int64_t gb = g0 + tid; gb < g1; gb += UB * BK_THREADS) {
+    float2 m2[UB];
+    int2 rd[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
+      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
+      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = gb + (int64_t)u * BK_THREADS;
+      int x0, x1, y0, y1;
+      if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
+      for_each_bucket(C == 1 ? 0 : (int)(g / N), x0, x1, y0, y1, bw, tile_h,
+                      [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+    }
   }
   __syncthreads();
   // reserve this workgroup's range in every bucket it feeds (one atomic per bucket)
@@ -225,20 +254,37 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     hist[b] = 0;   // becomes the local cursor
   }
   __syncthreads();
-  for (int64_t g = g0 + tid; g < g1; g += BK_THREADS) {
-    int x0, x1, y0, y1;
-    if (!tile_rect(means2d, radii, g, tile_w, tile_h, x0, x1, y0, y1)) continue;
-    const int c = C == 1 ? 0 : (int)(g / N);
-    const float d = depths[g];
-    const PairGauss p = load_pair_gauss(means2d, conics, opacities, opac_per_camera, g, N, C);
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x) {
-        const int m = pair_mask_of(p, x, y);
-        if (TIGHT && m == 0) continue;
-        const int b = (c * tile_h + y) * bw + x / BK_TILES;
-        const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
-        if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), d, (uint32_t)g, m | (p.clamp ? 16 : 0));
-      }
+  for (int64_t gb = g0 + tid; gb < g1; gb += UB * BK_THREADS) {
+    float2 m2[UB];
+    int2 rd[UB];
+    float dd[UB], op[UB], cn[UB][3];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
+      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
+      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
+      dd[u] = depths[g];
+      cn[u][0] = conics[g * 3];
+      cn[u][1] = conics[g * 3 + 1];
+      cn[u][2] = conics[g * 3 + 2];
+      op[u] = opacities[(opac_per_camera || C == 1) ? g : (g % N)];
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = gb + (int64_t)u * BK_THREADS;
+      int x0, x1, y0, y1;
+      if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
+      const int c = C == 1 ? 0 : (int)(g / N);
+      const PairGauss p = make_pair_conic(m2[u].x, m2[u].y, cn[u][0], cn[u][1], cn[u][2], op[u]);
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+          const int m = pair_mask_of(p, x, y);
+          if (TIGHT && m == 0) continue;
+          const int b = (c * tile_h + y) * bw + x / BK_TILES;
+          const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
+          if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), dd[u], (uint32_t)g, m | (p.clamp ? 16 : 0));
+        }
+    }
   }
   __syncthreads();
   for (int b = tid; b < n_buckets; b += BK_THREADS) {
@@ -355,14 +401,14 @@ __device__ __forceinline__ void tile_order_body(int n, const int32_t *tile_offse
   __syncthreads();
   for (int t = tid; t < n; t += nthreads) atomicAdd(&hist[cls(t)], 1);
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int b = 0; b < ORD_BUCKETS; ++b) {
-      const int c = hist[b];
-      hist[b] = run;
-      run += c;
-    }
-  }
+  // exclusive prefix over the classes: thread b adds up the classes before its own (broadcast LDS
+  // reads, all classes in parallel; one thread walking the 256 classes serially was most of this
+  // launch's 8 us)
+  int run = 0;
+  if (tid < ORD_BUCKETS)
+    for (int b = 0; b < tid; ++b) run += hist[b];
+  __syncthreads();
+  if (tid < ORD_BUCKETS) hist[tid] = run;
   __syncthreads();
   for (int t = tid; t < n; t += nthreads) tile_order[atomicAdd(&hist[cls(t)], 1)] = t;
 }
@@ -464,7 +510,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
 // tile_order (longest list first) from finished tile offsets; one workgroup.
 static inline int bk_grid(int64_t total, int64_t *chunk) {
   int g = (int)ceil_div64(total, 4096);
-  if (g > 256) g = 256;
+  if (g > 256) g = 256;   // (512 / 1024 workgroups measured: no difference, profiles/r03_emit_knockouts.log)
   if (g < 1) g = 1;
   *chunk = ceil_div64(total, g);
   return g;

@@ -13,6 +13,12 @@
 #include "gs_math.h"
 #include "raster_common.h"
 
+#ifndef GSR_PBWD_BLOCKS
+#define GSR_PBWD_BLOCKS 3   // 256-thread workgroups per CU the projection backward is register-allocated for
+                           // (168 VGPRs + 32 B of scratch instead of 177: 0.320 -> 0.309 ms, profiles/r03_ab_project_bwd_blocks.log)
+#endif
+
+
 namespace gsr {
 
 // Wave-cooperative read of the 64 consecutive shN rows [first_row, first_row + 64) (45 floats
@@ -64,12 +70,45 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
                    float *__restrict__ conics, float *__restrict__ compensations,
                    float *__restrict__ colors_out, int color_stride, int depth_channel,
                    int activations, float *__restrict__ opacities_out, int tile_w, int tile_h,
-                   int32_t *__restrict__ tile_counts, float *__restrict__ records) {
-  __shared__ float sBand[4 * 64 * 21];   // per-wave shN band slabs (coop_load_band)
+                   int32_t *__restrict__ tile_counts, float *__restrict__ records, int prefetch_rows) {
+  // Per-wave LDS slab for the shN coefficients of the wave's 64 Gaussians (dynamic: 4 x 64 x 45
+  // floats with `prefetch_rows`, 4 x 64 x 21 otherwise).
+  // prefetch_rows (all three bands needed, i.e. sh_degree 3): the 64 rows are one contiguous
+  // 11.5 KB block, requested FIRST, by LDS-DMA (16 bytes per lane, no registers), so that it
+  // travels while the parameters are loaded and projected; lane l then reads its row at
+  // slab + l*45 (45 is odd: bank-conflict free). 11.5 KB per wave hold the kernel at 3 waves/SIMD,
+  // which is enough once every request of a wave is issued up front: 0.084 -> 0.072 ms
+  // (profiles/r03_ab_project_fwd_slab.log). Round 2 had filled the same slab with register loads
+  // AFTER the projection and lost to the band-wise reads below (0.101 -> 0.112 ms); those remain
+  // for degrees 1 and 2, which need 9 or 24 of the 45 floats only.
+  extern __shared__ __attribute__((aligned(16))) float sBand[];
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
   int c = (C == 1) ? 0 : (int)(g / N);   // (64-bit division only with several cameras)
   int i = (int)(g - (int64_t)c * N);
+  bool slab_ready = false;
+  if (prefetch_rows) {
+    const int lane = threadIdx.x & 63;
+    const bool whole = (i - lane >= 0) && (i - lane + 63 < N);
+    slab_ready = whole;
+    if (slab_ready) {
+      float *slab = &sBand[(threadIdx.x >> 6) * (64 * 45)];
+      const float *src = shN + (int64_t)(i - lane) * 45;
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < 64 * 45 / 4) dma_16B(src + 4 * idx, slab + 256 * it);
+      }
+    }
+  }
+  // (sh0 row requested with the other parameters, not after the projection)
+  float c0v[3] = {0.f, 0.f, 0.f};
+  if (colors_out && sh_degree >= 0) {
+    const float *c0p = sh0 + (int64_t)i * sh0_stride;
+    c0v[0] = c0p[0];
+    c0v[1] = c0p[1];
+    c0v[2] = c0p[2];
+  }
   gs::Camera cam = gs::load_camera(viewmats + c * 16, Ks + c * 9);
   float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
   float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
@@ -111,8 +150,24 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     float r = 0.f, gg = 0.f, b = 0.f;
     const int lane = threadIdx.x & 63;
     // every lane of the wave has a row of the same camera and the rows are the reference's 45 floats
-    const bool banded = sh_degree > 0 && shN_stride == 45 && (i - lane >= 0) && (i - lane + 63 < N);
-    if (banded) {
+    const bool banded = !prefetch_rows && sh_degree > 0 && shN_stride == 45 && (i - lane >= 0) && (i - lane + 63 < N);
+    if (slab_ready) {
+      GSR_WAIT_VMEM();
+      if (p.rx > 0) {
+        const float *cn = &sBand[(threadIdx.x >> 6) * (64 * 45)] + lane * 45;
+        float dx = mean[0] - campos[c * 3 + 0];
+        float dy = mean[1] - campos[c * 3 + 1];
+        float dz = mean[2] - campos[c * 3 + 2];
+        float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
+        gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
+                     [&](int k, float bk, float, float, float) {
+                       const float *ck = (k == 0) ? c0v : cn + (k - 1) * 3;
+                       r += bk * ck[0];
+                       gg += bk * ck[1];
+                       b += bk * ck[2];
+                     });
+      }
+    } else if (banded) {
       if (__any(p.rx > 0)) {
         float *slab = &sBand[(threadIdx.x >> 6) * (64 * 21)];
         const int64_t first = (int64_t)(i - lane);
@@ -120,7 +175,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
         float dy = mean[1] - campos[c * 3 + 1];
         float dz = mean[2] - campos[c * 3 + 2];
         float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
-        const float *c0 = sh0 + (int64_t)i * sh0_stride;
+        const float *c0 = c0v;
         const float *cn = slab;
         gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
                      [&](int k, float bk, float, float, float) {
@@ -146,7 +201,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       float dy = mean[1] - campos[c * 3 + 1];
       float dz = mean[2] - campos[c * 3 + 2];
       float inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
-      const float *c0 = sh0 + (int64_t)i * sh0_stride;
+      const float *c0 = c0v;
       const float *cn = shN + (int64_t)i * shN_stride;
       gs::sh_visit(sh_degree, dx * inv, dy * inv, dz * inv,
                    [&](int k, float bk, float, float, float) {
@@ -174,7 +229,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 // and the parameters back in gsr_adam_step), each thread applies the Adam update of its
 // Gaussian right here; the shN block is updated in the transposed (coalesced) domain.
 template <bool FUSE_ADAM>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, GSR_PBWD_BLOCKS)
 project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ viewmats,
                    const float *__restrict__ Ks, const float *__restrict__ campos, int width,
@@ -471,12 +526,16 @@ extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *qu
   int64_t total = (int64_t)C * N;
   GSR_REQUIRE(total / 256 + 1 < 2147483647LL, "project_fwd: C*N too large");
   dim3 grid((unsigned)gsr::ceil_div64(total, 256));
-  hipLaunchKernelGGL(gsr::project_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, C, N, means,
+  // all three shN bands needed and the rows are the reference's 45 floats, 16-byte aligned: prefetch
+  // the wave's whole block (see the kernel); else the band-wise reads
+  const int prefetch_rows = colors_out && sh_degree >= 3 && shN_stride == 45 && ((((uintptr_t)shN) & 15) == 0);
+  const size_t lds = sizeof(float) * 4 * 64 * (prefetch_rows ? 45 : 21);
+  hipLaunchKernelGGL(gsr::project_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, C, N, means,
                      quats, scales, opacities, viewmats, Ks, campos, width, height, eps2d,
                      near_plane, far_plane, radius_clip, calc_compensations, sh_degree, sh0,
                      sh0_stride, shN, shN_stride, radii, means2d, depths, conics, compensations,
                      colors_out, color_stride, colors_out ? depth_channel : -1, activations,
-                     opacities_out, tile_w, tile_h, tile_counts, records);
+                     opacities_out, tile_w, tile_h, tile_counts, records, prefetch_rows);
   GSR_CHECK_LAUNCH("project_fwd");
   return GSR_OK;
 }
