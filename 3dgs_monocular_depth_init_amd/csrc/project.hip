@@ -13,6 +13,9 @@
 #include "gs_math.h"
 #include "raster_common.h"
 
+#ifndef GSR_ADAM_UNROLL
+#define GSR_ADAM_UNROLL 4
+#endif
 #ifndef GSR_PBWD_BLOCKS
 #define GSR_PBWD_BLOCKS 3   // 256-thread workgroups per CU the projection backward is register-allocated for
                            // (168 VGPRs + 32 B of scratch instead of 177: 0.320 -> 0.309 ms, profiles/r03_ab_project_bwd_blocks.log)
@@ -403,7 +406,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       float4 *V4 = reinterpret_cast<float4 *>(af.v[AF_SHN] + base);
       const float4 *G4 = reinterpret_cast<const float4 *>(slab);
       const float ss = af.step_size[AF_SHN], bc2 = af.bc2_sqrt[AF_SHN];
-#pragma unroll 4
+#pragma unroll GSR_ADAM_UNROLL
       for (int it = 0; it < 12; ++it) {
         const int idx = it * 64 + lane;
         if (idx < 64 * 45 / 4) {

@@ -408,18 +408,23 @@ def main():
             cycles = kc["GRBM_GUI_ACTIVE"] / 8.0
             cpi = cycles * 1024 / kc["SQ_INSTS_VALU"]
             ref = {}
-            ub = ROOT / "profiles" / "r02_valu_rate.jsonl"
+            # cycles per wave64 VALU instruction per SIMD the hardware sustains, by instruction
+            # stream, 4 waves per SIMD, all CUs busy, 256-instruction loop bodies
+            # (tools/ubench/valu_rate_long.hip; round 2's 16-instruction bodies read 2.5 for the
+            # plain stream: loop overhead and a register-bank conflict of that particular loop)
+            ub = ROOT / "profiles" / "r03_valu_rate_long.jsonl"
             if ub.exists():
                 for ln in ub.read_text().splitlines():
                     r = json.loads(ln)
-                    if r["chip"].startswith("all") and r["waves_per_simd"] == 4:
-                        ref[r["mode"]] = r["cycles_per_inst_per_simd"]
+                    if r["waves_per_simd"] == 4 and r["valu_per_trip"] >= 128:
+                        ref[r["mode"]] = r["cycles_per_inst_per_simd_median"]
+            plain = ref.get("mul_add_mix") or ref.get("chain1")
             valu_issue = {"insts_per_launch": int(kc["SQ_INSTS_VALU"]), "simds": 1024,
                           "cycles_per_launch": cycles, "cycles_per_inst_per_simd": cpi,
-                          "ubench_4_waves_per_simd": {k: ref.get(k) for k in ("indep_fma", "chain1", "exp_quarter",
-                                                                             "composite1", "composite2")},
-                          "ubench_source": "profiles/r02_valu_rate.jsonl",
-                          "frac_of_indep_fma_rate": (ref["indep_fma"] / cpi) if "indep_fma" in ref else None}
+                          "ubench_4_waves_per_simd": {k: ref.get(k) for k in ("mul_add_mix", "chain1", "indep_fma",
+                                                                             "exp_quarter", "pk_fma")},
+                          "ubench_source": "profiles/r03_valu_rate_long.jsonl",
+                          "frac_of_plain_valu_rate": (plain / cpi) if plain else None}
 
     if rank == 0:
         line = {
@@ -430,7 +435,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("c4: 1M-Gaussian seeded scene S(1e6,seed 0), 100 synthetic cameras "
-                             "1920x1080 f=1200, 1 view/rank/step, SH degree 3, "
+                             "1920x1080 f=1200, 1 view/rank/step, SH degree 3, tight tile lists "
+                             "(runner.rasterize_splats default: pairs whose alpha >= 1/255 ellipse misses the tile are not listed), "
                              + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
                              + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
