@@ -37,7 +37,7 @@ SIGNATURES = {
     "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p],
     "gsr_pair_masks": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
-    "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p],
+    "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "gsr_rasterize_bwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
 }
 SIGNATURES["gsr_ssim_workspace_doubles"] = [_i, _i, _i, _i]
@@ -94,6 +94,7 @@ SIGNATURES.update({
     "gsr_dn_avgpool3s2": [_i, _i, _i, _p, _i, _p, _i, _p],
     "gsr_dn_slice": [_i64, _i, _p, _i, _p, _i, _f, _i, _i, _p],
     "gsr_dn_gru_gate": [_i64, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "gsr_dn_swiglu": [_i64, _i, _p, _i, _p, _i, _p],
     "gsr_dn_depth_expectation": [_i64, _i, _p, _i, _f, _f, _f, _p, _i, _p],
     "gsr_dn_normal_head": [_i64, _p, _i, _p, _i, _p, _i, _p],
     "gsr_dn_convex_upsample": [_i, _i, _i, _p, _p, _i, _f, _f, _f, _p, _p, _p, _p],

@@ -825,6 +825,22 @@ slice_kernel(int64_t P, int C, const h16 *__restrict__ in, int ldi, h16 *__restr
   }
 }
 
+// SwiGLU gate of the ViT-giant FFN (ViT_DINO_reg.py SwiGLUFFN.forward :335-345):
+// out[p, c] = silu(x12[p, c]) * x12[p, h + c], c < h (x12 = w12(x), two halves of 2h columns)
+__global__ void __launch_bounds__(256)
+swiglu_kernel(int64_t P, int h, const h16 *__restrict__ x12, int ldx, h16 *__restrict__ out, int ldo) {
+  const int64_t total = P * (h / 2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (h / 2)) * 2;
+    const int64_t p = i / (h / 2);
+    const h16 *row = x12 + p * ldx;
+    const float a0 = (float)row[c], a1 = (float)row[c + 1], b0 = (float)row[h + c], b1 = (float)row[h + c + 1];
+    out[p * ldo + c] = (h16)(a0 / (1.0f + __expf(-a0)) * b0);
+    out[p * ldo + c + 1] = (h16)(a1 / (1.0f + __expf(-a1)) * b1);
+  }
+}
+
 // ConvGRU gate algebra (RAFTDepthNormalDPTDecoder5.py ConvGRU.forward):
 //   stage 0: z = sigmoid(zr[:, 0:C] + cz), r = sigmoid(zr[:, C:2C] + cr); writes z and r*h
 //   stage 1: q = tanh(qin + cq); h = (1 - z) h + z q
@@ -1182,6 +1198,16 @@ extern "C" int gsr_dn_slice(int64_t P, int C, const void *in, int ldi, void *out
   hipLaunchKernelGGL(slice_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, P, C,
                      (const h16 *)in, ldi, (h16 *)out, ldo, a, accumulate, act);
   GSR_CHECK_LAUNCH("dn_slice");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_swiglu(int64_t P, int h, const void *x12, int ldx, void *out, int ldo, void *stream) {
+  GSR_REQUIRE(P >= 0 && h > 0 && h % 2 == 0 && ldx >= 2 * h && ldo >= h, "dn_swiglu: bad sizes");
+  if (P == 0) return GSR_OK;
+  GSR_REQUIRE(x12 && out, "dn_swiglu: null pointer");
+  hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(P * (h / 2))), dim3(256), 0, (hipStream_t)stream, P, h,
+                     (const h16 *)x12, ldx, (h16 *)out, ldo);
+  GSR_CHECK_LAUNCH("dn_swiglu");
   return GSR_OK;
 }
 

@@ -77,8 +77,14 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   // R = T_final*(v_alpha_out - <background, v_out>) - <buf, v_out>, where buf is the colour
   // accumulated behind the current Gaussian: only its dot product with v_out is ever
   // needed, so one scalar per pixel replaces the CH-vector
-  float px[4], py[2], T[4], R[4], vout[4][CH];
+  // pixel q of this lane: x = px[q & 1], y = py[q >> 1] (the lane's column / row in the left / right and
+  // upper / lower quadrants). No per-pixel copy of x is needed: a pixel that takes no part (outside
+  // the image, or nothing blended into it) is parked by T = R = v_out = 0, with which every
+  // contribution below is an exact zero (T stays 0 under T *= 1/(1-a), a <= 0.999).
+  float px[2], py[2], T[4], R[4], vout[4][CH];
   int last[4], qmax[4];
+  px[0] = (float)(tx0 + lx) + 0.5f;
+  px[1] = px[0] + 8.0f;
   py[0] = (float)(ty0 + ly) + 0.5f;
   py[1] = py[0] + 8.0f;
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
@@ -87,9 +93,8 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int x = tx0 + 8 * (q & 1) + lx, y = ty0 + 8 * (q >> 1) + ly;
-    px[q] = (float)x + 0.5f;
     last[q] = -1;
-    T[q] = 1.f;
+    T[q] = 0.f;
     R[q] = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) vout[q][k] = 0.f;
@@ -108,11 +113,13 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     }
     qmax[q] = __builtin_amdgcn_readfirstlane(wave_max_i32(last[q]));
     max_last = max(max_last, qmax[q]);
-    // a pixel outside the image or one nothing was blended into takes no part: park it
-    // (sigma -> huge, alpha -> 0 for every Gaussian) so that it never holds back the
-    // fast path below
+    // a pixel outside the image or one nothing was blended into takes no part: park it (see
+    // above) so that it never holds back the fast path below
     if (last[q] < s) {
-      px[q] = PIX_DONE;
+      T[q] = 0.f;
+      R[q] = 0.f;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) vout[q][k] = 0.f;
       last[q] = 0x7fffffff;
     }
     my_min_last = min(my_min_last, last[q]);
@@ -211,7 +218,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
         for (int h = 0; h < 2; ++h) {
          const int q = 2 * r + h;
          if (qm & (1u << q)) {   // scalar branch
-          const float dx = Ac.x - px[q];
+          const float dx = Ac.x - px[h];
           const float sg = sigma_l2(Ac.z, dx, Br, Cr);
           const float vis = __builtin_amdgcn_exp2f(-sg);
           const float ov = opac * vis;

@@ -35,7 +35,8 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                   int tile_h, const int32_t *__restrict__ tile_offsets,
                   const int32_t *__restrict__ tile_order,
                   const int32_t *__restrict__ pair_ids, float *__restrict__ render_colors,
-                  float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
+                  float *__restrict__ render_alphas, int32_t *__restrict__ last_ids,
+                  float4 *__restrict__ zero_rows, int64_t n_zero16) {
   // staged batches: row r = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | -}.
   // 2 x 2 KB per wave; the workgroup IS one wave, so no barriers: the DMA into buffer (k+1)&1 is
   // issued after the loop over batch k-1 has consumed its last read of that buffer.
@@ -43,6 +44,14 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   __shared__ uint32_t sPw[PW_SLOTS][RBATCH];
 
   if ((int)blockIdx.x >= n_tiles) return;
+  // The backward's gradient rows ([C*N, 16] floats) must start at zero. This kernel is bound by
+  // instruction issue, not by HBM, so every wave clears its slice of them on the side (a handful of
+  // fire-and-forget 1 KB stores) instead of a 64 MB fill launch in front of the backward.
+  if (zero_rows) {
+    const int64_t per = (n_zero16 + n_tiles - 1) / n_tiles;           // 16-byte pieces per workgroup
+    const int64_t z0 = (int64_t)blockIdx.x * per, z1 = min(n_zero16, z0 + per);
+    for (int64_t z = z0 + threadIdx.x; z < z1; z += 64) zero_rows[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   const int tiles_per_cam = tile_w * tile_h;
   const int cam = tile / tiles_per_cam;
@@ -191,10 +200,12 @@ template <int CH>
 static int launch_fwd(int n_tiles, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *pair_ids, float *render_colors,
-                      float *render_alphas, int32_t *last_ids, hipStream_t stream) {
+                      float *render_alphas, int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
+                      hipStream_t stream) {
   hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), occupancy_pad("GSR_FWD_LDS_PAD"), stream, n_tiles, records,
                      backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
-                     pair_ids, render_colors, render_alphas, last_ids);
+                     pair_ids, render_colors, render_alphas, last_ids, reinterpret_cast<float4 *>(zero_rows),
+                     n_zero_rows * (GSR_GRAD_ROW / 4));
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
 }
@@ -235,7 +246,8 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
                                  int width, int height, int tile_w, int tile_h,
                                  const int32_t *tile_offsets, const int32_t *tile_order,
                                  const int32_t *pair_ids, float *render_colors,
-                                 float *render_alphas, int32_t *last_ids, void *stream) {
+                                 float *render_alphas, int32_t *last_ids, float *zero_rows,
+                                 int64_t n_zero_rows, void *stream) {
   GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
               "rasterize_fwd: tile grid %dx%d does not match %dx%d image", tile_w, tile_h, width,
@@ -245,13 +257,15 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
   GSR_REQUIRE(tile_offsets && render_colors && render_alphas && last_ids,
               "rasterize_fwd: null pointer");
   GSR_REQUIRE(((uintptr_t)records & 15) == 0, "rasterize_fwd: records must be 16-byte aligned");
+  GSR_REQUIRE(!zero_rows || (n_zero_rows >= 0 && ((uintptr_t)zero_rows & 15) == 0),
+              "rasterize_fwd: zero_rows must be 16-byte aligned");
   int n_tiles = C * tile_w * tile_h;
   hipStream_t st = (hipStream_t)stream;
 #define GSR_FWD_CASE(K)                                                                         \
   case K:                                                                                       \
     return gsr::launch_fwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
                               tile_offsets, tile_order, pair_ids, render_colors,                \
-                              render_alphas, last_ids, st);
+                              render_alphas, last_ids, zero_rows, n_zero_rows, st);
   switch (CH) {
     GSR_FWD_CASE(1)
     GSR_FWD_CASE(2)

@@ -41,6 +41,12 @@ CONFIGS = {
                  decoder_channels=[48, 96, 192, 384, 384], hidden=[48, 48, 48, 48], iters=4),
     "vitl": dict(embed_dim=1024, depth=24, heads=16, feature_channels=[256, 512, 1024, 1024],
                  decoder_channels=[128, 256, 512, 1024, 1024], hidden=[128, 128, 128, 128], iters=8),
+    # vit_giant2_reg (ViT_DINO_reg.py:1246-1260): 1536-d, 40 blocks, 24 heads, SwiGLU FFN (hidden
+    # 4096 = 8-aligned 2/3 of 4*1536). The decoder's channel plan is the published
+    # dino_vit_giant2_reg.dpt_raft.py (1.5x the large one); that file is NOT vendored in the
+    # reference tree, so this row of the plan is taken from the public Metric3D repository.
+    "vitg": dict(embed_dim=1536, depth=40, heads=24, feature_channels=[384, 768, 1536, 1536],
+                 decoder_channels=[192, 384, 768, 1536, 1536], hidden=[192, 192, 192, 192], iters=8),
 }
 PATCH = 14
 N_REG = 4
@@ -155,15 +161,20 @@ class Metric3DNet:
         self.blocks = []
         for i in range(self.depth):
             p = f"blocks.0.{i}." if f"blocks.0.{i}.norm1.weight" in sd else f"blocks.{i}."
-            self.blocks.append(dict(
+            blk = dict(
                 n1w=f32(sd[p + "norm1.weight"]), n1b=f32(sd[p + "norm1.bias"]),
                 qkv=_Lin(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], dev),
                 proj=_Lin(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], dev),
                 ls1=f32(sd[p + "ls1.gamma"]),
                 n2w=f32(sd[p + "norm2.weight"]), n2b=f32(sd[p + "norm2.bias"]),
-                fc1=_Lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dev),
-                fc2=_Lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dev),
-                ls2=f32(sd[p + "ls2.gamma"])))
+                ls2=f32(sd[p + "ls2.gamma"]))
+            if p + "mlp.w12.weight" in sd:       # SwiGLUFFN (ViT_DINO_reg.py:300-345): vit_giant2_reg
+                blk.update(w12=_Lin(sd[p + "mlp.w12.weight"], sd[p + "mlp.w12.bias"], dev),
+                           w3=_Lin(sd[p + "mlp.w3.weight"], sd[p + "mlp.w3.bias"], dev))
+            else:                                # Mlp (fc1 -> GELU -> fc2)
+                blk.update(fc1=_Lin(sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], dev),
+                           fc2=_Lin(sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], dev))
+            self.blocks.append(blk)
         self.norm_w, self.norm_b = f32(sd["norm.weight"]), f32(sd["norm.bias"])
 
     def _prep_decoder(self, sd):
@@ -308,7 +319,10 @@ class Metric3DNet:
         xn = self._buf("xn", (n_tok, D))
         qkv = self._buf("qkv", (n_tok, 3 * D))
         att = self._buf("att", (n_tok, D))
-        hid = self._buf("hid", (n_tok, 4 * D))
+        swiglu = bool(self.blocks) and "w12" in self.blocks[0]
+        h_ffn = self.blocks[0]["w3"].k if swiglu else 4 * D
+        hid = self._buf("hid", (n_tok, _ceil(h_ffn, 64)))
+        h12 = self._buf("h12", (n_tok, 2 * h_ffn)) if swiglu else None
         n_pad = _ceil(n_tok, 64)
         vt = self._buf("vt", (self.heads * 64 * n_pad,))
         scale = 64 ** -0.5
@@ -322,8 +336,13 @@ class Metric3DNet:
             self.gemm(n_tok, b["proj"], att, D, gamma=b["ls1"], residual=x, ldr=D, out32=x, ldo32=D)
             call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n2w"]), ptr(b["n2b"]), 1e-6, ptr(xn), D,
                  None, 0, 0, _st())
-            self.gemm(n_tok, b["fc1"], xn, D, act=ACT_GELU, out16=hid, ldo16=4 * D)
-            self.gemm(n_tok, b["fc2"], hid, 4 * D, gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
+            if swiglu:
+                self.gemm(n_tok, b["w12"], xn, D, out16=h12, ldo16=2 * h_ffn)
+                call("gsr_dn_swiglu", n_tok, h_ffn, ptr(h12), 2 * h_ffn, ptr(hid), hid.shape[1], _st())
+                self.gemm(n_tok, b["w3"], hid, hid.shape[1], gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
+            else:
+                self.gemm(n_tok, b["fc1"], xn, D, act=ACT_GELU, out16=hid, ldo16=4 * D)
+                self.gemm(n_tok, b["fc2"], hid, 4 * D, gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
         tokens = torch.empty(n_tok, D, dtype=torch.float16, device=self.dev)
         call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(self.norm_w), ptr(self.norm_b), 1e-6, ptr(tokens), D,
              None, 0, 0, _st())

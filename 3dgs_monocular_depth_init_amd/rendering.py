@@ -438,6 +438,11 @@ def bucket_layout_ok(C: int, N: int, tile_w: int, tile_h: int) -> bool:
 EXACT_TILE_ORDER = os.environ.get("GSR_EXACT_TILE_ORDER", "1") == "1"
 
 
+# The backward's [C*N, 16] gradient rows are cleared by the compositing forward on the side (True)
+# or by a fill launch in front of the backward (False).
+CLEAR_ROWS_IN_FORWARD = os.environ.get("GSR_CLEAR_ROWS_IN_FORWARD", "1") == "1"
+
+
 class _IsectState:
     """Per-device memory of the last frame's intersection count: lets the next frame
     size its buffers and launch emit / sort / compositing WITHOUT waiting for its own
@@ -543,9 +548,15 @@ class _Rasterize(torch.autograd.Function):
         render_colors = torch.empty(C, height, width, CH, dtype=torch.float32, device=dev)
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        # the backward's gradient rows are cleared by the forward kernel itself, on the side (it is
+        # not HBM-bound): no 64 MB fill launch in front of the backward
+        rows = None
+        if CLEAR_ROWS_IN_FORWARD and C * N > 0 and C * tile_w * tile_h > 0 and any(ctx.needs_input_grad[:4]):
+            rows = torch.empty(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
         call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
              tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
-             ptr(render_alphas), ptr(last_ids), _stream())
+             ptr(render_alphas), ptr(last_ids), ptr(rows), C * N, _stream())
+        ctx.rows = rows
         ctx.cfg = cfg
         ctx.shape = (C, N, color_stride, per_cam)
         ctx.save_for_backward(means2d, backgrounds, tile_offsets, tile_order, pair_ids,
@@ -568,7 +579,9 @@ class _Rasterize(torch.autograd.Function):
         v_render_colors = _f32c(v_render_colors)
         if v_render_alphas is not None:          # None: the kernel takes a null pointer as zeros
             v_render_alphas = _f32c(v_render_alphas)
-        rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
+        rows, ctx.rows = ctx.rows, None      # cleared by the forward; a second backward gets fresh zeros
+        if rows is None:
+            rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
         call("gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
              tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_alphas),
              ptr(last_ids), ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows),

@@ -266,7 +266,9 @@ int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrou
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *pair_ids,
                       float *render_colors, float *render_alphas, int32_t *last_ids,
-                      void *stream);
+                      float *zero_rows /* NULL, or the [n_zero_rows, 16] grad_rows buffer the backward of
+                                          this render will accumulate into: cleared here, on the side */,
+                      int64_t n_zero_rows, void *stream);
 int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *pair_ids,
@@ -274,7 +276,8 @@ int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrou
                       const float *v_render_colors,
                       const float *v_render_alphas /* NULL = no gradient on the alphas */,
                       int absgrad,
-                      float *grad_rows /* [C*N,16], zeroed by caller, accumulated */, void *stream);
+                      float *grad_rows /* [C*N,16], zero on entry (by the caller, or by the forward's
+                                          zero_rows), accumulated */, void *stream);
 
 /* ---------------------------------------------------------------------------
  * A8 / F2: fused multi-tensor Adam over the Gaussian parameters, one launch
@@ -560,6 +563,9 @@ int gsr_dn_avgpool3s2(int Hi, int Wi, int C, const void *in, int ldi, void *out,
 /* out[p, 0:C] = act(a * in[p, 0:C] (+ out[p, 0:C])) over strided channel slices. */
 int gsr_dn_slice(int64_t P, int C, const void *in, int ldi, void *out, int ldo, float a, int accumulate,
                  int act, void *stream);
+/* SwiGLU gate of vit_giant2_reg's FFN (ViT_DINO_reg.py:335-345): out[p, c] = silu(x12[p, c]) *
+ * x12[p, h + c] for c < h; fp16 in and out. */
+int gsr_dn_swiglu(int64_t P, int h, const void *x12, int ldx, void *out, int ldo, void *stream);
 /* ConvGRU gate algebra (decoder :318-330). stage 0: zr = [convz(hx) | convr(hx)] [P,2C], ctx =
  * [cz | cr | cq] [P,3C]: writes z = sigmoid(.) and rh = sigmoid(.) * h. stage 1: zr = convq([r*h, x])
  * [P,C]: h = (1 - z) h + z tanh(zr + cq). */

@@ -46,10 +46,10 @@ class NS(dict):
     __getattr__ = dict.__getitem__
 
 
-def vit(embed_dim, heads, depth):
+def vit(embed_dim, heads, depth, ffn_layer="mlp"):
     m = V.DinoVisionTransformer(img_size=518, patch_size=14, embed_dim=embed_dim, depth=depth, num_heads=heads,
                                 mlp_ratio=4, block_fn=V.partial(V.Block, attn_class=V.MemEffAttention),
-                                num_register_tokens=4).eval()
+                                num_register_tokens=4, ffn_layer=ffn_layer).eval()
     m.load_state_dict(DW.fill(m))
     return m
 
@@ -154,5 +154,12 @@ with torch.no_grad():
             a = full[f"{name}_{k}"].astype(np.float32)
             print(name, k, a.shape, float(np.abs(a).mean()), float(np.abs(a).max()))
         del enc, dec
+    # vit_giant2_reg's block (ViT_DINO_reg.py:1246-1260: 1536-d, 24 heads, ffn_layer='swiglu' -> SwiGLUFFN
+    # :300-345, hidden 4096), 4 of its 40 blocks (the full stack is 1.1 G parameters)
+    encG = vit(1536, 24, 4, ffn_layer="swiglu")
+    assert type(encG.blocks[0][0].mlp).__name__.startswith("SwiGLU"), type(encG.blocks[0][0].mlp)
+    featsG, _ = encG(img)
+    full["vitg4_tokens"] = featsG[0][0].numpy().astype(np.float16)
+    print("vitg4 tokens", full["vitg4_tokens"].shape, float(np.abs(full["vitg4_tokens"].astype(np.float32)).mean()))
 np.savez_compressed(HERE / "depthnet_full_golden.npz", **full)
 print("wrote depthnet_full_golden.npz")

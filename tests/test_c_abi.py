@@ -35,7 +35,7 @@ def test_ctypes_table_matches_header():
 def test_argument_errors_are_reported_without_a_gpu():
     pkg = importlib.import_module("3dgs_monocular_depth_init_amd")
     lib = pkg._lib.load()
-    rc = lib.gsr_rasterize_fwd(1, 9, None, None, 16, 16, 1, 1, *([None] * 7))
+    rc = lib.gsr_rasterize_fwd(1, 9, None, None, 16, 16, 1, 1, *([None] * 7), 0, None)
     assert rc == -1 and b"CH=9" in lib.gsr_last_error()
     import pytest
     with pytest.raises(pkg._lib.GsrastError):

@@ -183,16 +183,21 @@ def _close(got, ref, max_frac=3e-3, mean_frac=3e-3, what=""):
     assert float(err.mean()) <= mean_frac * float(ref.abs().mean()), (what, float(err.mean()), float(ref.abs().mean()))
 
 
-def _vit_shapes(D, depth):
+def _vit_shapes(D, depth, swiglu_hidden=0):
     s = {"cls_token": (1, 1, D), "pos_embed": (1, 1370, D), "register_tokens": (1, 4, D), "mask_token": (1, D),
          "patch_embed.proj.weight": (D, 3, 14, 14), "patch_embed.proj.bias": (D,), "norm.weight": (D,), "norm.bias": (D,)}
     for i in range(depth):
         p = f"blocks.0.{i}."
         s.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "attn.qkv.weight": (3 * D, D),
                   p + "attn.qkv.bias": (3 * D,), p + "attn.proj.weight": (D, D), p + "attn.proj.bias": (D,),
-                  p + "ls1.gamma": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
-                  p + "mlp.fc1.weight": (4 * D, D), p + "mlp.fc1.bias": (4 * D,), p + "mlp.fc2.weight": (D, 4 * D),
-                  p + "mlp.fc2.bias": (D,), p + "ls2.gamma": (D,)})
+                  p + "ls1.gamma": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,), p + "ls2.gamma": (D,)})
+        if swiglu_hidden:
+            h = swiglu_hidden
+            s.update({p + "mlp.w12.weight": (2 * h, D), p + "mlp.w12.bias": (2 * h,), p + "mlp.w3.weight": (D, h),
+                      p + "mlp.w3.bias": (D,)})
+        else:
+            s.update({p + "mlp.fc1.weight": (4 * D, D), p + "mlp.fc1.bias": (4 * D,),
+                      p + "mlp.fc2.weight": (D, 4 * D), p + "mlp.fc2.bias": (D,)})
     return s
 
 
@@ -367,6 +372,23 @@ def test_full_depth_networks_vs_reference_golden(N, name):
     # and the whole chain, encoder into decoder
     d2, c2, o2 = net.inference({"input": DW.image(112, 168)})
     _close(c2[0, 0], FG[f"{name}_conf"], max_frac=2e-2, mean_frac=1e-2, what=f"{name} e2e confidence")
+
+
+def test_vit_giant_swiglu_blocks_vs_reference_golden(N):
+    """vit_giant2_reg's block -- 1536-d, 24 heads, SwiGLU FFN with hidden 4096 (ViT_DINO_reg.py:1246-1260,
+    300-345) -- four blocks of it, against tokens recorded from the reference's module."""
+    D, heads, depth, hidden = 1536, 24, 4, 4096
+    cfg = dict(N.CONFIGS["vitg"], depth=depth)
+    sd = {"encoder." + k: v for k, v in DW.fill(_vit_shapes(D, depth, swiglu_hidden=hidden)).items()}
+    net = N.Metric3DNet.__new__(N.Metric3DNet)
+    net.cfg, net.dev, net.H, net.W, net._scratch = cfg, torch.device("cuda"), 112, 168, {}
+    net.gh, net.gw, net.D, net.heads, net.depth = 8, 12, D, heads, depth
+    net.n_tok = 1 + 4 + 96
+    net._prep_encoder({k[len("encoder."):]: v for k, v in sd.items()})
+    assert "w12" in net.blocks[0]
+    tokens = net.encode(DW.image(112, 168))
+    assert tokens.shape == (101, D)
+    _close(tokens, FG["vitg4_tokens"].astype(np.float32), max_frac=6e-3, mean_frac=4e-3, what="vitg4 tokens")
 
 
 def test_full_size_vitl_runs(N):
