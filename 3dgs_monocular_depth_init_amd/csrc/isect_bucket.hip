@@ -147,6 +147,21 @@ __device__ __forceinline__ int bk_block_exclusive_scan(int32_t *a, int n, int32_
   return tot;
 }
 
+#ifdef GSR_EMIT_TIMELINE
+// diagnostic build: s_memtime at the phase boundaries of bucket_emit_kernel, per workgroup
+__device__ unsigned long long *g_emit_timeline = nullptr;
+#define EMIT_STAMP(k)                                                                     \
+  do {                                                                                    \
+    __syncthreads();                                                                      \
+    if (threadIdx.x == 0 && g_emit_timeline) {                                            \
+      unsigned long long t_;                                                              \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      g_emit_timeline[8 * blockIdx.x + (k)] = t_;                                         \
+    }                                                                                     \
+  } while (0)
+#else
+#define EMIT_STAMP(k)
+#endif
 constexpr uint64_t BK_SENTINEL = ~0ull;   // a reserved slot no pair was written to (sorts last, skipped)
 constexpr int BK_ORDER_CLASSES = 64;
 
@@ -170,12 +185,17 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
   __shared__ int32_t cls[BK_ORDER_CLASSES], clt[BK_ORDER_CLASSES];
   const int tid = threadIdx.x;
+  EMIT_STAMP(0);
   for (int b = tid; b < n_buckets; b += BK_THREADS) {
     hist[b] = 0;
     base[b] = bucket_counts[b];
   }
   __syncthreads();
-  if (blockIdx.x == 0 && (bucket_order || tile_order)) {
+  // The LAST workgroup of the grid owns no Gaussians: it publishes what the sort pass and the host
+  // need (work orders, offsets, slot total) while the others scatter. (On workgroup 0, beside its
+  // share of the Gaussians, that job made it the kernel's critical path: +12 k cycles of 93 k.)
+  const bool publisher = blockIdx.x == gridDim.x - 1;
+  if (publisher && (bucket_order || tile_order)) {
     // work orders, longest first, in 64 length classes of the rectangle-rule counts: of the buckets
     // for the sort pass, and of the TILES for the compositing kernels (bucket by bucket: the 8 tiles
     // of a bucket are neighbours with lists of similar length; a tile-exact order needed a launch
@@ -212,7 +232,7 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     __syncthreads();
   }
   const int total_slots = bk_block_exclusive_scan(base, n_buckets, wave_tot);   // base = bucket offsets
-  if (blockIdx.x == 0) {
+  if (publisher) {
     for (int b = tid; b < n_buckets; b += BK_THREADS) bucket_offsets[b] = base[b];
     if (tid == 0) {
       bucket_offsets[n_buckets] = total_slots;
@@ -221,6 +241,8 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
       if (total_host) __hip_atomic_store(total_host, total_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  EMIT_STAMP(1);
+  if (publisher) return;
   const int64_t total = (int64_t)C * N;
   const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
   // Both passes over the workgroup's Gaussians take them FOUR per thread at a time, all loads of
@@ -246,14 +268,20 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     }
   }
   __syncthreads();
-  // reserve this workgroup's range in every bucket it feeds (one atomic per bucket)
-  for (int b = tid; b < n_buckets; b += BK_THREADS) {
+  EMIT_STAMP(2);
+  // reserve this workgroup's range in every bucket it feeds (one returning atomic per bucket; the
+  // workgroups walk the buckets from different starting points, so that at any moment they queue
+  // at different words)
+  for (int i = tid; i < n_buckets; i += BK_THREADS) {
+    int b = i + (int)blockIdx.x * 4;
+    b = b % n_buckets;
     const int h = hist[b];
     resv[b] = h;
     base[b] = (h > 0) ? base[b] + atomicAdd(&bucket_cursor[b], h) : 0;
     hist[b] = 0;   // becomes the local cursor
   }
   __syncthreads();
+  EMIT_STAMP(3);
   for (int64_t gb = g0 + tid; gb < g1; gb += UB * BK_THREADS) {
     float2 m2[UB];
     int2 rd[UB];
@@ -276,17 +304,20 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
       if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
       const int c = C == 1 ? 0 : (int)(g / N);
       const PairGauss p = make_pair_conic(m2[u].x, m2[u].y, cn[u][0], cn[u][1], cn[u][2], op[u]);
-      for (int y = y0; y < y1; ++y)
+      for (int y = y0; y < y1; ++y) {
+        const AxisTerms Y = axis_terms(p.my, p.sx, p.ky, (float)(y * GSR_TILE));   // shared by the row's tiles
         for (int x = x0; x < x1; ++x) {
-          const int m = pair_mask_of(p, x, y);
+          const int m = pair_quadrant_mask(p, axis_terms(p.mx, p.sy, p.kx, (float)(x * GSR_TILE)), Y);
           if (TIGHT && m == 0) continue;
           const int b = (c * tile_h + y) * bw + x / BK_TILES;
           const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
           if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), dd[u], (uint32_t)g, m | (p.clamp ? 16 : 0));
         }
+      }
     }
   }
   __syncthreads();
+  EMIT_STAMP(4);
   for (int b = tid; b < n_buckets; b += BK_THREADS) {
     const int h = resv[b], r = hist[b];
     if (h == 0) continue;
@@ -300,6 +331,7 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
     const int written = (int)(room <= 0 ? 0 : (room < r ? room : r));
     if (written > 0) atomicAdd(&real_counts[b], written);
   }
+  EMIT_STAMP(5);
 }
 
 // All-ascending bitonic network with virtual +inf padding (positions >= L). Pair
@@ -518,6 +550,14 @@ static inline int bk_grid(int64_t total, int64_t *chunk) {
 
 }  // namespace gsr
 
+#ifdef GSR_EMIT_TIMELINE
+extern "C" int gsr_debug_set_emit_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_emit_timeline), &p, sizeof(p)));
+  return GSR_OK;
+}
+#endif
+
 extern "C" int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int *n_buckets_out) {
   const int bw = gsr::ceil_div(tile_w, gsr::BK_TILES);
   if (bw_out) *bw_out = bw;
@@ -577,7 +617,7 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
               "bucket_emit: null pointer");
   GSR_REQUIRE(total == 0 || (means2d && radii && depths && conics && opacities), "bucket_emit: null pointer");
   int64_t chunk;
-  const int grid = gsr::bk_grid(total, &chunk);   // >= 1 workgroup even for an empty scene: it publishes the offsets
+  const int grid = gsr::bk_grid(total, &chunk) + 1;   // + the publisher workgroup (see the kernel)
   const size_t lds = 3 * sizeof(int32_t) * nb;
   if (tight)
     hipLaunchKernelGGL(gsr::bucket_emit_kernel<true>, dim3(grid), dim3(gsr::BK_THREADS), lds,

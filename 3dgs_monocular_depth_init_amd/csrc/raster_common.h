@@ -84,44 +84,46 @@ __device__ __forceinline__ PairConic make_pair_conic(float mx, float my, float a
   p.clamp = op > gs::ALPHA_MAX;
   return p;
 }
-__device__ __forceinline__ int pair_quadrant_mask(const PairConic &p, float tx0, float ty0) {
-  // per half h (0: pixels 0..7, 1: pixels 8..15) and axis: offsets of the mean from the first and
-  // last pixel centre, whether the mean lies inside the half's span, and the facing edge's offset
-  float lo[2][2], hi[2][2], de[2][2];
-  bool in[2][2];
-#pragma unroll
-  for (int ax = 0; ax < 2; ++ax)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float first = (ax == 0 ? tx0 : ty0) + (8.f * (float)h + 0.5f);
-      hi[ax][h] = (ax == 0 ? p.mx : p.my) - first;
-      lo[ax][h] = hi[ax][h] - 7.f;
-      in[ax][h] = lo[ax][h] * hi[ax][h] <= 0.f;
-      de[ax][h] = hi[ax][h] < 0.f ? hi[ax][h] : lo[ax][h];
-    }
-  // edge terms shared by the two quadrants of a column (vertical edges) / row (horizontal edges)
-  float vp[2], vk[2], hp[2], hk[2];
+// One axis of one tile: per half h (0: pixels 0..7, 1: pixels 8..15) the offsets of the mean from the
+// first and last pixel centre, whether the mean lies inside the half's span, and the terms of the
+// facing edge (offset de): pe = s * de (the minimiser along the edge), ke = k * de^2.
+// x axis: s = sy, k = kx (vertical edges); y axis: s = sx, k = ky (horizontal edges). Computed once
+// per tile column / tile row and shared by the tiles of a rectangle (the emit pass walks rows).
+struct AxisTerms {
+  float lo[2], hi[2], pe[2], ke[2];
+  bool in[2];
+};
+__device__ __forceinline__ AxisTerms axis_terms(float mean, float s, float k, float t0) {
+  AxisTerms a;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    vp[h] = p.sy * de[0][h];              // dy* on the vertical edge of x-half h
-    vk[h] = p.kx * de[0][h] * de[0][h];
-    hp[h] = p.sx * de[1][h];              // dx* on the horizontal edge of y-half h
-    hk[h] = p.ky * de[1][h] * de[1][h];
+    a.hi[h] = mean - (t0 + (8.f * (float)h + 0.5f));
+    a.lo[h] = a.hi[h] - 7.f;
+    a.in[h] = a.lo[h] * a.hi[h] <= 0.f;
+    const float de = a.hi[h] < 0.f ? a.hi[h] : a.lo[h];
+    a.pe[h] = s * de;
+    a.ke[h] = k * de * de;
   }
+  return a;
+}
+__device__ __forceinline__ int pair_quadrant_mask(const PairConic &p, const AxisTerms &X, const AxisTerms &Y) {
   int qmask = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int xh = q & 1, yh = q >> 1;
-    const float tv = __builtin_amdgcn_fmed3f(vp[xh], lo[1][yh], hi[1][yh]) - vp[xh];
-    const float sv = fmaf(p.hc * tv, tv, vk[xh]);
-    const float th = __builtin_amdgcn_fmed3f(hp[yh], lo[0][xh], hi[0][xh]) - hp[yh];
-    const float sh = fmaf(p.ha * th, th, hk[yh]);
+    const float tv = __builtin_amdgcn_fmed3f(X.pe[xh], Y.lo[yh], Y.hi[yh]) - X.pe[xh];
+    const float sv = fmaf(p.hc * tv, tv, X.ke[xh]);
+    const float th = __builtin_amdgcn_fmed3f(Y.pe[yh], X.lo[xh], X.hi[xh]) - Y.pe[yh];
+    const float sh = fmaf(p.ha * th, th, Y.ke[yh]);
     // inside along x: only the horizontal edge faces the mean; inside along y: only the vertical one
-    float m = fminf(in[0][xh] ? 3.0e38f : sv, in[1][yh] ? 3.0e38f : sh);
-    m = (in[0][xh] && in[1][yh]) ? 0.f : m;
+    float m = fminf(X.in[xh] ? 3.0e38f : sv, Y.in[yh] ? 3.0e38f : sh);
+    m = (X.in[xh] && Y.in[yh]) ? 0.f : m;
     qmask |= (m <= p.tau_m) ? (1 << q) : 0;
   }
   return qmask;
+}
+__device__ __forceinline__ int pair_quadrant_mask(const PairConic &p, float tx0, float ty0) {
+  return pair_quadrant_mask(p, axis_terms(p.mx, p.sy, p.kx, tx0), axis_terms(p.my, p.sx, p.ky, ty0));
 }
 
 // Packed per-(camera,Gaussian) compositing record, one 64-byte row (= one cache line / one

@@ -143,7 +143,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                 const bool ok = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
                 float a = ok ? (NOCLAMP ? ov : fminf(gs::ALPHA_MAX, ov)) : 0.f;
                 float nT = fmaf(-a, T[q], T[q]);
-                if (__any(nT <= gs::T_THRESHOLD)) {   // rare: a pixel finishes at this Gaussian
+                if (__builtin_expect(__any(nT <= gs::T_THRESHOLD), 0)) {   // rare: a pixel finishes at this Gaussian
                   const bool stop = nT <= gs::T_THRESHOLD;   // only possible when ok
                   a = stop ? 0.f : a;
                   nT = stop ? T[q] : nT;
