@@ -184,8 +184,48 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   int32_t *hist = lds, *base = lds + n_buckets, *resv = lds + 2 * n_buckets;
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
   __shared__ int32_t cls[BK_ORDER_CLASSES], clt[BK_ORDER_CLASSES];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   EMIT_STAMP(0);
+  // Both passes over the workgroup's Gaussians take them FOUR per thread and trip. With the usual
+  // grid that is ONE trip, and its values are loaded right here, ahead of the scan, the histogram
+  // and the reservation, whose latencies they then hide under (loaded where they are used they
+  // cost 7 us of exposed round trips, profiles/r03_emit_knockouts.log).
+  constexpr int UB = 4;
+  const int64_t total = (int64_t)C * N;
+  const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
+  const int64_t gw0 = g0 + (tid & ~63);
+  const bool one_trip = g0 + (int64_t)UB * BK_THREADS >= g1;
+  float2 m2[UB];
+  int2 rd[UB];
+  float dd[UB], op[UB], cn[UB][3];
+  auto load_rects = [&](int64_t gb) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
+      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
+      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
+    }
+  };
+  auto load_rest = [&](int64_t gb) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
+#if defined(GSR_EMIT_KO) && GSR_EMIT_KO == 5
+      dd[u] = m2[u].x; cn[u][0] = 0.01f; cn[u][1] = 0.f; cn[u][2] = 0.01f; op[u] = 0.5f;
+#else
+      dd[u] = depths[g];
+      cn[u][0] = conics[g * 3];
+      cn[u][1] = conics[g * 3 + 1];
+      cn[u][2] = conics[g * 3 + 2];
+      op[u] = opacities[(opac_per_camera || C == 1) ? g : (g % N)];
+#endif
+    }
+  };
+  const bool owns = blockIdx.x != gridDim.x - 1 && g0 < g1;
+  if (owns) {
+    load_rects(gw0 + lane);
+    if (one_trip) load_rest(gw0 + lane);
+  }
   for (int b = tid; b < n_buckets; b += BK_THREADS) {
     hist[b] = 0;
     base[b] = bucket_counts[b];
@@ -243,21 +283,9 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   }
   EMIT_STAMP(1);
   if (publisher) return;
-  const int64_t total = (int64_t)C * N;
-  const int64_t g0 = (int64_t)blockIdx.x * chunk, g1 = min(total, g0 + chunk);
-  // Both passes over the workgroup's Gaussians take them FOUR per thread at a time, all loads of
-  // the four issued before the first is used (a thread walking its Gaussians one by one exposes a
-  // memory round trip per Gaussian and pass; measured: no gain on c4, kept for its shape).
-  constexpr int UB = 4;
-  for (int64_t gb = g0 + tid; gb < g1; gb += UB * BK_THREADS) {
-    float2 m2[UB];
-    int2 rd[UB];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
-      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
-      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
-    }
+  for (int64_t gw = gw0; gw < g1; gw += UB * BK_THREADS) {
+    const int64_t gb = gw + lane;
+    if (gw != gw0) load_rects(gb);
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int64_t g = gb + (int64_t)u * BK_THREADS;
@@ -282,37 +310,82 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   }
   __syncthreads();
   EMIT_STAMP(3);
-  for (int64_t gb = g0 + tid; gb < g1; gb += UB * BK_THREADS) {
-    float2 m2[UB];
-    int2 rd[UB];
-    float dd[UB], op[UB], cn[UB][3];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int64_t g = min(gb + (int64_t)u * BK_THREADS, g1 - 1);
-      m2[u] = *reinterpret_cast<const float2 *>(means2d + g * 2);
-      rd[u] = *reinterpret_cast<const int2 *>(radii + g * 2);
-      dd[u] = depths[g];
-      cn[u][0] = conics[g * 3];
-      cn[u][1] = conics[g * 3 + 1];
-      cn[u][2] = conics[g * 3 + 2];
-      op[u] = opacities[(opac_per_camera || C == 1) ? g : (g % N)];
+  // Pass 2 proper. A Gaussian touches 2.7 tiles on average but a few touch dozens: a lane that
+  // walked its own (rows x tiles) nest kept the other 63 waiting for the largest one of the wave
+  // (measured: 49 k of the workgroup's 81 k cycles). So the wave POOLS its pairs: an exclusive
+  // scan of the lanes' pair counts numbers them, lane l takes pairs l, l+64, ... of the pool and
+  // fetches the owning Gaussian's values from the owner's registers (ds_bpermute).
+#if defined(GSR_EMIT_KO) && GSR_EMIT_KO == 4
+  if (keys == nullptr)
+#endif
+  for (int64_t gw = gw0; gw < g1; gw += UB * BK_THREADS) {   // wave-uniform trip count
+    const int64_t gb = gw + lane;
+    if (!one_trip) {
+      load_rects(gb);
+      load_rest(gb);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       const int64_t g = gb + (int64_t)u * BK_THREADS;
-      int x0, x1, y0, y1;
-      if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
-      const int c = C == 1 ? 0 : (int)(g / N);
-      const PairGauss p = make_pair_conic(m2[u].x, m2[u].y, cn[u][0], cn[u][1], cn[u][2], op[u]);
-      for (int y = y0; y < y1; ++y) {
-        const AxisTerms Y = axis_terms(p.my, p.sx, p.ky, (float)(y * GSR_TILE));   // shared by the row's tiles
-        for (int x = x0; x < x1; ++x) {
-          const int m = pair_quadrant_mask(p, axis_terms(p.mx, p.sy, p.kx, (float)(x * GSR_TILE)), Y);
-          if (TIGHT && m == 0) continue;
-          const int b = (c * tile_h + y) * bw + x / BK_TILES;
-          const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
-          if (q < capacity) keys[q] = bk_key(x & (BK_TILES - 1), dd[u], (uint32_t)g, m | (p.clamp ? 16 : 0));
+      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+      const bool ok = g < g1 && tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1);
+      const int nx = ok ? x1 - x0 : 0, n = ok ? nx * (y1 - y0) : 0;
+      int incl = n;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      const int excl = incl - n, pool = __shfl(incl, 63, 64);
+      const PairConic own = make_pair_conic(m2[u].x, m2[u].y, cn[u][0], cn[u][1], cn[u][2], op[u]);   // once per Gaussian
+      const int xy = x0 | (y0 << 16) | (own.clamp ? (int)0x80000000 : 0);   // tile_h < 2^15
+      for (int j0 = 0; j0 < pool; j0 += 64) {
+        const int j = j0 + lane;
+        int L = 0;   // owner = the LAST lane whose first pair is <= j (lanes without pairs share their successor's start)
+#pragma unroll
+        for (int step = 32; step; step >>= 1) {
+          const int e = __shfl(excl, L + step, 64);
+          if (e <= j) L += step;
         }
+        const int k = j - __shfl(excl, L, 64);
+        const int oxy = __shfl(xy, L, 64), onx = __shfl(nx, L, 64);
+        PairConic p;
+        p.mx = __shfl(own.mx, L, 64);
+        p.my = __shfl(own.my, L, 64);
+        p.ha = __shfl(own.ha, L, 64);
+        p.hc = __shfl(own.hc, L, 64);
+        p.sx = __shfl(own.sx, L, 64);
+        p.sy = __shfl(own.sy, L, 64);
+        p.kx = __shfl(own.kx, L, 64);
+        p.ky = __shfl(own.ky, L, 64);
+        p.tau_m = __shfl(own.tau_m, L, 64);
+        const float odc = __shfl(dd[u], L, 64);
+        p.clamp = oxy < 0;
+        if (j >= pool) continue;
+        int row = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)onx));
+        row -= (row * onx > k);
+        row += ((row + 1) * onx <= k);
+        const int x = (oxy & 0xffff) + (k - row * onx), y = ((oxy >> 16) & 0x7fff) + row;
+        const int64_t og = gw + (int64_t)u * BK_THREADS + L;
+#if defined(GSR_EMIT_KO) && GSR_EMIT_KO == 3
+        const int m = 15;
+#else
+        const int m = pair_quadrant_mask(p, (float)(x * GSR_TILE), (float)(y * GSR_TILE));
+#endif
+        if (TIGHT && m == 0) continue;
+        const int c = C == 1 ? 0 : (int)(og / N);
+        const int b = (c * tile_h + y) * bw + x / BK_TILES;
+#if defined(GSR_EMIT_KO) && GSR_EMIT_KO == 2
+        const int64_t q = (int64_t)base[b];
+#else
+        const int64_t q = (int64_t)base[b] + atomicAdd(&hist[b], 1);
+#endif
+        const uint64_t key = bk_key(x & (BK_TILES - 1), odc, (uint32_t)og, m | (p.clamp ? 16 : 0));
+#if defined(GSR_EMIT_KO) && (GSR_EMIT_KO == 1 || GSR_EMIT_KO == 2)
+        if (key == 0x1234567ull) keys[q] = key;   // knock-out: never true, keeps the key computation alive
+#else
+        if (q < capacity) keys[q] = key;
+#endif
       }
     }
   }

@@ -493,3 +493,38 @@ def test_tight_lists_long_rectangles(R):
     live = ((m0["pair_ids"] >> 28) & 15) != 0
     assert torch.equal(m0["pair_ids"][live], m1["pair_ids"])
     assert torch.equal(rc0, rc1) and torch.equal(ra0, ra1)
+
+
+def test_bucketed_lists_more_than_one_trip_per_workgroup(R):
+    """More than 2^20 (camera, Gaussian) pairs: every workgroup of the bucketed builder's count and
+    emit passes walks its Gaussians in more than one trip (the first trip's values are loaded at
+    the kernel top, the later ones where they are used). Lists and pair words must equal the
+    per-tile builder's, and the tight lists must be those lists without the mask-0 pairs."""
+    C, N, W, H = 2, 600_000, 640, 368
+    tw, th = W // 16, H // 16
+    gen = torch.Generator().manual_seed(5)
+    m2d = torch.rand(C, N, 2, generator=gen) * torch.tensor([W + 40.0, H + 40.0]) - 20.0
+    radii = torch.randint(0, 14, (C, N, 2), generator=gen, dtype=torch.int32)
+    radii[:, ::97] = torch.randint(20, 90, radii[:, ::97].shape, generator=gen, dtype=torch.int32)
+    radii[:, ::5] = 0                                                        # culled Gaussians
+    depths = torch.rand(C, N, generator=gen) * 9.0 + 0.2
+    s = (radii.float().clamp(min=1.0) / 3.0) ** 2                            # conic ~ 3-sigma extent
+    con = torch.stack([1.0 / s[..., 0], (torch.rand(C, N, generator=gen) - 0.5) * 0.6 / (s[..., 0] * s[..., 1]).sqrt(),
+                       1.0 / s[..., 1]], -1)
+    opa = torch.rand(N, generator=gen) * 0.98 + 0.01
+    opa[::11] = 0.9995                                                       # clamp flag set
+    m2d, radii, depths, con, opa = (t.cuda().contiguous() for t in (m2d, radii, depths, con, opa))
+    assert C * N > (1 << 20) and R.bucket_layout_ok(C, N, tw, th)
+    off_a, _, ids_a, _, _, pairs_a = R.isect_tiles_sorted(m2d, radii, depths, tw, th, want_tiles_per_gauss=True,
+                                                          conics=con, opacities=opa)
+    off_b, _, ids_b, _, _, pairs_b = R.isect_tiles_sorted(m2d, radii, depths, tw, th, conics=con, opacities=opa)
+    assert torch.equal(off_a, off_b) and torch.equal(ids_a, ids_b) and torch.equal(pairs_a, pairs_b)
+    off_t, _, ids_t, _, _, pairs_t = R.isect_tiles_sorted(m2d, radii, depths, tw, th, conics=con, opacities=opa,
+                                                          tight=True)
+    keep = (pairs_a >> 28) & 15 != 0
+    assert 0.3 < float(keep.float().mean()) < 0.98
+    assert torch.equal(pairs_t, pairs_a[keep]) and torch.equal(ids_t, ids_a[keep])
+    tile_of = torch.repeat_interleave(torch.arange(C * tw * th, device=off_a.device),
+                                      (off_a[1:] - off_a[:-1]).long())
+    cnt = torch.zeros(C * tw * th, dtype=torch.long, device=off_a.device).index_add_(0, tile_of[keep], torch.ones_like(tile_of[keep]))
+    assert torch.equal((off_t[1:] - off_t[:-1]).long(), cnt)
