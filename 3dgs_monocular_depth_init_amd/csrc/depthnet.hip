@@ -18,6 +18,8 @@
 //                      HBM-bound element-wise kernels around the GEMMs.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace gsr {
@@ -434,6 +436,558 @@ gemm256_kernel(GemmArgs p) {
         if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
       }
     }
+}
+
+// ---- 256x256x64 tile, FOUR waves of 128x128 outputs, one wave per SIMD ------------------------------
+// The step beyond the ping-pong kernel above: a 128x128 wave tile needs 8 fragment reads (8 KB) per 16
+// MFMAs -- 32 KB of LDS reads per K-step and CU (256 LDS cycles) against 512 MFMA cycles per SIMD, plus
+// the LDS-DMA writes of the next tile (another 128 cycles per K-step): the LDS pipe is at 75 % when the
+// matrix pipe is full, so the matrix pipe is what bounds it. With one wave per SIMD nothing hides a
+// wave's own latencies, so the wave is software-pipelined by hand:
+//   * fragments double-buffered in registers: K-step s issues the reads of step s+1, then its 16 MFMAs;
+//   * ONE barrier per K-tile, between K-steps 2 and 3: by then the wave has read all of tile u, and it
+//     has waited for its own DMA of tile u+1 (issued a whole tile earlier); after the barrier tile u+1
+//     is complete for everyone and tile u's buffer is free, so the DMA of tile u+2 is issued into it
+//     and K-step 3 reads step 0 of tile u+1 under its MFMAs. The matrix pipe only sees the barrier skew.
+// The DMAs are asm statements (raster_common.h: the compiler would otherwise drain them before the
+// next LDS read). Accumulators: 16 tiles x 16 = 256 registers (AGPRs), ~110 VGPRs beside them.
+__device__ __forceinline__ void dn_dma_16B(const void *src_lane, uint32_t lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src_lane), "s"(lds_dst_uniform)
+      : "memory");
+}
+// the same with a wave-uniform 64-bit base (SGPR pair) and a 32-bit byte offset per lane
+__device__ __forceinline__ void dn_dma_16B_off(const void *base_uniform, uint32_t byte_off_lane, uint32_t lds_dst_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(byte_off_lane), "s"(base_uniform), "s"(lds_dst_uniform)
+      : "memory");
+}
+template <int ACT, bool CONV>
+__global__ void __launch_bounds__(256)
+gemm_w128_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM2 + BN2) * BK];   // 2 x 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
+  int wg = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
+    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+  }
+  const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // staging: wave w, instruction i moves rows (8w + i)*8 .. +7 of A and of B; lane -> (row, physical chunk)
+  const int srow = lane >> 3, pch = lane & 7;
+  const h16 *ga[8], *gb[8];
+  int pix_y[8], pix_x[8], lch[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (wave * 8 + i) * 8 + srow;
+    lch[i] = (pch ^ ((r >> 1) & 7)) * 8;
+    const int m = min(m0 + r, p.M - 1);
+    if (CONV) {
+      pix_y[i] = m / p.cW;
+      pix_x[i] = m - pix_y[i] * p.cW;
+      ga[i] = nullptr;
+    } else {
+      ga[i] = p.A + (int64_t)m * p.lda + lch[i];
+    }
+    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void *)&smem[0][0]);
+  auto stage = [&](int buf, int k0) {
+    int ky = 0, kx = 0, c0 = 0;
+    bool tap_ok = true;
+    if (CONV) {
+      const int tap = k0 / p.cC;
+      c0 = k0 - tap * p.cC;
+      ky = tap / p.cKS;
+      kx = tap - ky * p.cKS;
+      tap_ok = tap < p.cKS * p.cKS;
+    }
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(lds0 + (uint32_t)buf * (uint32_t)((BM2 + BN2) * BK * 2) + (uint32_t)wave * (64 * BK * 2)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const h16 *src;
+      if (CONV) {
+        const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
+        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
+      } else {
+        src = ga[i] + k0;
+      }
+      dn_dma_16B(src, base + (uint32_t)i * (8 * BK * 2));
+      dn_dma_16B(gb[i] + k0, base + (uint32_t)(BM2 * BK * 2) + (uint32_t)i * (8 * BK * 2));
+    }
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  half8 fa[2][4], fb[2][4];   // [register buffer][tile]
+
+  const int swz = (lr >> 1) & 7;
+  auto read_frags = [&](int buf, int s, int rb) {
+    const h16 *sA = smem[buf] + (wm * 128 + lr) * BK, *sB = smem[buf] + BM2 * BK + (wn * 128 + lr) * BK;
+    const int c = ((2 * s + lh) ^ swz) << 3;
+#if defined(GSR_W128_KO) && GSR_W128_KO == 3
+    if (p.M != 12345) return;     // knock-out: no fragment reads (registers keep whatever they hold)
+#endif
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[rb][t] = *reinterpret_cast<const half8 *>(sA + t * 32 * BK + c);
+      fb[rb][t] = *reinterpret_cast<const half8 *>(sB + t * 32 * BK + c);
+    }
+  };
+  auto mfma_step = [&](int rb) {
+#if defined(GSR_W128_KO) && GSR_W128_KO == 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i], fb[rb][i], acc[i][i], 0, 0, 0);
+    for (int i = 0; i < 3; ++i) acc[i][i + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i + 1], fb[rb][i], acc[i][i + 1], 0, 0, 0);
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i], fb[rb][j], acc[i][j], 0, 0, 0);
+#endif
+  };
+  // 8 fragment reads spread under 16 MFMAs
+#define GSR_INTERLEAVE()                                   \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     \
+  }
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  if (nk > 1) {
+    stage(1, BK);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed (tile 1's 16 DMAs may be in flight)
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, 0);
+  for (int u = 0; u < nk; ++u) {
+    const int buf = u & 1;
+    read_frags(buf, 1, 1);
+    mfma_step(0);
+    GSR_INTERLEAVE();
+    read_frags(buf, 2, 0);
+    mfma_step(1);
+    GSR_INTERLEAVE();
+    read_frags(buf, 3, 1);
+    mfma_step(0);
+    GSR_INTERLEAVE();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#if !defined(GSR_W128_KO) || GSR_W128_KO != 1
+    if (u + 2 < nk) stage(buf, (u + 2) * BK);
+#endif
+    if (u + 1 < nk) read_frags(buf ^ 1, 0, 0);
+    mfma_step(1);
+    GSR_INTERLEAVE();
+  }
+#undef GSR_INTERLEAVE
+
+  // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
+  auto emit = [&](const f32x16 &a, int i, int j) {
+    const int n = n0 + wn * 128 + j * 32 + lr;
+    const int mb = m0 + wm * 128 + i * 32 + 4 * lh;
+    if (n >= p.N) {
+      if (n < p.pad_to) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) p.out16[(int64_t)m * p.ldo16 + n] = (h16)0.f;
+        }
+      }
+      return;
+    }
+    const float b = p.bias ? p.bias[n] : 0.f;
+    const float g = p.gamma ? p.gamma[n] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      if (m >= p.M) continue;
+      float v = act_fn<ACT>(a[r] + b) * g;
+      if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+      if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
+      if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
+      if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
+    }
+  };
+#define GSR_EMIT_ROW(I) emit(acc[I][0], I, 0); emit(acc[I][1], I, 1); emit(acc[I][2], I, 2); emit(acc[I][3], I, 3)
+  GSR_EMIT_ROW(0);
+  GSR_EMIT_ROW(1);
+  GSR_EMIT_ROW(2);
+  GSR_EMIT_ROW(3);
+#undef GSR_EMIT_ROW
+}
+
+// ---- 256x256x64 tile in eight phases per two K-tiles (the guide's verified structure, section 5) -------
+// Eight waves as 2 (rows) x 4 (columns), 128x64 outputs each, v_mfma_f32_16x16x32_f16. A K-tile is
+// staged as FOUR half-tiles of 16 KB -- A0 / A1 = the upper / lower 64 rows of each wave row's 128,
+// B0 / B1 = the left / right 32 columns of each wave column's 64 -- and computed as four QUADRANTS
+// (64 x 32 outputs x K = 64 = 16 MFMAs per wave): (A0,B0) (A0,B1) (A1,B1) (A1,B0); a phase reads the
+// fragments its quadrant is missing (12 / 4 / 8 / 0 ds_read_b128), stages ONE half-tile seven ahead of
+// the phase number (two DMA instructions per wave), and issues its 16 MFMAs. The two wave rows run one
+// barrier apart, so in every barrier interval one wave per SIMD issues MFMAs while the other reads
+// and stages. Eight half-tile slots (two K-tiles); the DMAs are waited for ONCE per K-tile with a
+// counted vmcnt(6) that leaves three half-tiles in flight across the barriers:
+//   half-tile q = 4t + i in order [A0 B0 B1 A1] is read in phase 4t + {0,0,1,2}[i]; phase P stages
+//   q = P + 7 into slot q & 7, whose previous tenant q - 8 was last read in a phase <= P - 1 and whose
+//   reads were retired (lgkmcnt(0)) before that phase's barrier (write-after-read); the wait in phase
+//   4t + 3 retires all of tile t + 1, both wave rows pass a barrier after their wait before anyone reads
+//   it in phase 4t + 4 (read-after-write: an LDS-DMA is ordered for a ds_read only by the issuing
+//   wave's vmcnt followed by a barrier).
+// Operands are passed to the MFMA swapped (W fragment first), so a lane ends up with FOUR CONSECUTIVE
+// columns of one output row: 8-byte fp16 / 16-byte fp32 stores in the epilogue.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef GSR_GEMM_TIMELINE
+// diagnostic build: s_memrealtime (100 MHz) at kernel start / tile 0 landed / main loop done / epilogue done, per workgroup
+__device__ unsigned long long *g_gemm_timeline = nullptr;
+#define GEMM_STAMP(k)                                                                      \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && g_gemm_timeline) {                                             \
+      unsigned long long t_;                                                               \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+      g_gemm_timeline[4 * (blockIdx.y * gridDim.x + blockIdx.x) + (k)] = t_;               \
+    }                                                                                      \
+  } while (0)
+#else
+#define GEMM_STAMP(k)
+#endif
+template <int ACT, bool CONV>
+__global__ void __launch_bounds__(512)
+gemm8p_kernel(GemmArgs p) {
+  constexpr int HT = 128 * BK;                     // halves per half-tile (16 KB)
+  __shared__ __attribute__((aligned(1024))) h16 smem[8 * HT];   // 128 KB: slot = (tile & 1) * 4 + i
+  GEMM_STAMP(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
+  int wg = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
+    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
+  }
+  const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
+
+  // staging: a half-tile is 16 units of 8 rows; wave w moves units 2w and 2w+1. lane -> (row, physical chunk).
+  // local row r of an A half h is tile row (r >> 6) * 128 + h * 64 + (r & 63); of a B half h it is
+  // tile column (r >> 5) * 64 + h * 32 + (r & 31).
+  const int srow = lane >> 3, pch = lane & 7;
+  uint32_t ga[2][2], gb[2][2];                    // [half][unit of this wave]: BYTE offsets from p.A / p.W
+  int pix_y[2][2], pix_x[2][2], lchs[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + srow;
+    lchs[j] = (pch ^ ((r >> 1) & 7)) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+      if (CONV) {
+        pix_y[h][j] = m / p.cW;
+        pix_x[h][j] = m - pix_y[h][j] * p.cW;
+        ga[h][j] = 0;
+      } else {
+        ga[h][j] = (uint32_t)(((int64_t)m * p.lda + lchs[j]) * 2);      // < 4 GB: checked by the launcher
+      }
+      const int n = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
+      gb[h][j] = (uint32_t)(((int64_t)n * p.K + lchs[j]) * 2);
+    }
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void *)&smem[0]);
+  const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)wave * (2 * 8 * BK * 2)));
+  // stage half-tile i (0: A0, 1: B0, 2: B1, 3: A1) of K-tile `tile`
+  auto stage = [&](int tile, int i) {
+    const int k0 = tile * BK;
+    const uint32_t dst = lds_w + (uint32_t)(((tile & 1) * 4 + i) * HT * 2);
+    const bool isA = i == 0 || i == 3;
+    const int h = (i == 0 || i == 1) ? 0 : 1;
+    int ky = 0, kx = 0, c0 = 0;
+    bool tap_ok = true;
+    if (CONV && isA) {
+      const int tap = k0 / p.cC;
+      c0 = k0 - tap * p.cC;
+      ky = tap / p.cKS;
+      kx = tap - ky * p.cKS;
+      tap_ok = tap < p.cKS * p.cKS;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t d = dst + (uint32_t)j * (8 * BK * 2);
+      if (!isA) {
+        dn_dma_16B_off(p.W + k0, gb[h][j], d);
+      } else if (CONV) {
+        const int iy = pix_y[h][j] + ky - p.cPad, ix = pix_x[h][j] + kx - p.cPad;
+        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+        dn_dma_16B(ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lchs[j] : p.zero_page, d);
+      } else {
+        dn_dma_16B_off(p.A + k0, ga[h][j], d);
+      }
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+  half8 af[4][2], bf[2][2][2];   // A: [row tile of the half][k-step]; B: [half][column tile][k-step]
+
+  // fragment reads: lane l holds row (l & 15), halves 8 * (l >> 4) .. + 7 of k-step ks (32 wide)
+  const int l15 = lane & 15, lq = lane >> 4, swz = (l15 >> 1) & 7;
+  const int a_row = wr * 64 + l15, b_row = wc * 32 + l15;
+  auto read_a = [&](int slot_halves) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        af[m][ks] = *reinterpret_cast<const half8 *>(smem + slot_halves + (a_row + m * 16) * BK + (((lq + 4 * ks) ^ swz) << 3));
+  };
+  auto read_b = [&](int slot_halves, int h) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        bf[h][n][ks] = *reinterpret_cast<const half8 *>(smem + slot_halves + (b_row + n * 16) * BK + (((lq + 4 * ks) ^ swz) << 3));
+  };
+  // quadrant (ah, bh) with the B fragments of register set `set`
+  auto mfma_quadrant_x = [&](int ah, int bh, int set) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[ah * 4 + m][bh * 2 + n] =
+              __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[set][n][ks], af[m][ks], acc[ah * 4 + m][bh * 2 + n], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mfma_quadrant = [&](int ah, int bh) { mfma_quadrant_x(ah, bh, bh); };
+#define GSR_BAR()                        \
+  __builtin_amdgcn_sched_barrier(0);     \
+  __builtin_amdgcn_s_barrier();          \
+  __builtin_amdgcn_sched_barrier(0)
+#define GSR_LOADS_DONE()                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  GSR_BAR()
+
+  const int nk = p.K / BK, NQ = 4 * nk;
+  // prologue: half-tiles 0..6 in flight, tile 0 waited for
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+    if (q < NQ) stage(q >> 2, q & 3);
+  if (NQ >= 7) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GSR_BAR();
+  GEMM_STAMP(1);
+  if (wr == 1) { GSR_BAR(); }                      // the lower wave row runs one barrier behind
+  // one K-tile; PAR = t & 1 at compile time (the slot addresses are then constants)
+  // (tried: reads balanced 8 / 4 / 8 / 4 by fetching the next tile's B0 fragments in phase 3, with a
+  // counted wait in every phase -- 5 % slower at 4096^3, 251 registers instead of 222)
+  auto tile = [&](int t, auto par_c) {
+    constexpr int sb = decltype(par_c)::value * 4 * HT;     // this tile's slots, in halves
+    read_b(sb + 1 * HT, 0);                                 // phase 4t: (A0, B0); stage (tile t + 1, A1)
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(sb + 0 * HT);
+    if (t + 1 < nk) stage(t + 1, 3);
+    GSR_LOADS_DONE();
+    mfma_quadrant(0, 0);
+    GSR_BAR();
+    read_b(sb + 2 * HT, 1);                                 // phase 4t + 1: (A0, B1); stage (tile t + 2, A0)
+    if (t + 2 < nk) stage(t + 2, 0);
+    GSR_LOADS_DONE();
+    mfma_quadrant(0, 1);
+    GSR_BAR();
+    read_a(sb + 3 * HT);                                    // phase 4t + 2: (A1, B1); stage (tile t + 2, B0)
+    if (t + 2 < nk) stage(t + 2, 1);
+    GSR_LOADS_DONE();
+    mfma_quadrant(1, 1);
+    GSR_BAR();
+    // phase 4t + 3: (A1, B0), fragments already in registers; stage (tile t + 2, B1); the one DMA wait of
+    // the K-tile: everything but the last three half-tiles, i.e. all of tile t + 1
+    if (t + 2 < nk) {
+      stage(t + 2, 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    GSR_BAR();
+    mfma_quadrant(1, 0);
+    GSR_BAR();
+  };
+  for (int t = 0; t + 1 < nk; t += 2) {
+    tile(t, std::integral_constant<int, 0>{});
+    tile(t + 1, std::integral_constant<int, 1>{});
+  }
+  if (nk & 1) tile(nk - 1, std::integral_constant<int, 0>{});
+  if (wr == 0) { GSR_BAR(); }
+  GEMM_STAMP(2);
+#undef GSR_BAR
+#undef GSR_LOADS_DONE
+
+  // Epilogue through LDS. In the accumulator layout a store instruction covers 16 rows x 32 bytes --
+  // 16 partial lines per instruction, 8 us of store issue for a 256x256 fp16 tile (in-kernel timeline).
+  // Each wave instead writes its 128x64 outputs, 64 rows at a time, as fp32 into a private 16 KB of the
+  // (now idle) staging memory -- rows of 256 B, 16-byte chunks XOR-ed with the row so that both the
+  // accumulator-layout writes and the row-layout reads are conflict-free -- and reads them back with
+  // 8 lanes per row, 8 consecutive columns per lane: bias / LayerScale are per-lane constants, the
+  // residual loads and the stores are whole 128-byte (fp16) or 256-byte (fp32) row segments.
+  {
+    const int nw0 = n0 + wc * 64;                                        // this wave's 64 columns
+    const bool rows_ok = (!p.out16 || ((((uintptr_t)p.out16) & 15) == 0 && (p.ldo16 & 7) == 0)) &&
+                         (!p.out32 || ((((uintptr_t)p.out32) & 15) == 0 && (p.ldo32 & 3) == 0)) &&
+                         (!p.residual || ((((uintptr_t)p.residual) & 15) == 0 && (p.ldr & 3) == 0)) &&
+                         (!p.residual16 || ((((uintptr_t)p.residual16) & 15) == 0 && (p.ldr16 & 7) == 0)) &&
+                         ((((uintptr_t)p.bias) | ((uintptr_t)p.gamma)) & 15) == 0;
+    if (rows_ok && nw0 + 64 <= p.N) {                                    // wave-uniform
+      float *cw = reinterpret_cast<float *>(smem) + wave * (HT / 2);     // 16 KB = [64 rows][64 floats]
+      const int rr = lane >> 3, c8 = lane & 7, ncol = nw0 + c8 * 8;
+      f32x4 bia[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gam[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+      if (p.bias) {
+        bia[0] = *reinterpret_cast<const f32x4 *>(p.bias + ncol);
+        bia[1] = *reinterpret_cast<const f32x4 *>(p.bias + ncol + 4);
+      }
+      if (p.gamma) {
+        gam[0] = *reinterpret_cast<const f32x4 *>(p.gamma + ncol);
+        gam[1] = *reinterpret_cast<const f32x4 *>(p.gamma + ncol + 4);
+      }
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const int row = mt * 16 + l15, ch = (nt >> 1) * 8 + (nt & 1) * 4 + lq;
+            *reinterpret_cast<f32x4 *>(cw + row * 64 + ((ch ^ l15) << 2)) = acc[ph * 4 + mt][nt];
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rr;
+          const int m = m0 + wr * 128 + ph * 64 + row;
+          f32x4 v[2];
+          v[0] = *reinterpret_cast<const f32x4 *>(cw + row * 64 + (((2 * c8) ^ (row & 15)) << 2));
+          v[1] = *reinterpret_cast<const f32x4 *>(cw + row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2));
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[hh][r] = act_fn<ACT>(v[hh][r] + bia[hh][r]) * gam[hh][r];
+          if (p.residual) {
+            const float *rp = p.residual + (int64_t)m * p.ldr + ncol;
+            v[0] += *reinterpret_cast<const f32x4 *>(rp);
+            v[1] += *reinterpret_cast<const f32x4 *>(rp + 4);
+          }
+          if (p.residual16) {
+            const half8 r16 = *reinterpret_cast<const half8 *>(p.residual16 + (int64_t)m * p.ldr16 + ncol);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r >> 2][r & 3] += (float)r16[r];
+          }
+          if (p.out32) {
+            float *op = p.out32 + (int64_t)m * p.ldo32 + ncol;
+            *reinterpret_cast<f32x4 *>(op) = v[0];
+            *reinterpret_cast<f32x4 *>(op + 4) = v[1];
+          }
+          if (p.out16) {
+            half8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (h16)v[r >> 2][r & 3];
+            *reinterpret_cast<half8 *>(p.out16 + (int64_t)m * p.ldo16 + ncol) = o;
+          }
+        }
+      }
+#ifdef GSR_GEMM_TIMELINE
+      __syncthreads();
+      GEMM_STAMP(3);
+#endif
+      return;
+    }
+  }
+  // (partial column tiles, unaligned rows: element-wise in the accumulator layout)
+  const bool vec_ok = (!p.out16 || ((((uintptr_t)p.out16) & 7) == 0 && (p.ldo16 & 3) == 0)) &&
+                      (!p.out32 || ((((uintptr_t)p.out32) & 15) == 0 && (p.ldo32 & 3) == 0)) &&
+                      (!p.residual || ((((uintptr_t)p.residual) & 15) == 0 && (p.ldr & 3) == 0)) &&
+                      (!p.residual16 || ((((uintptr_t)p.residual16) & 7) == 0 && (p.ldr16 & 3) == 0)) &&
+                      ((((uintptr_t)p.bias) | ((uintptr_t)p.gamma)) & 15) == 0;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = n0 + wc * 64 + (nt >> 1) * 32 + (nt & 1) * 16 + 4 * lq;
+    const bool fast = vec_ok && n + 3 < p.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, gam4 = {1.f, 1.f, 1.f, 1.f};
+    if (fast) {
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + n);    // n % 4 == 0; cudaMalloc-aligned vectors
+      if (p.gamma) gam4 = *reinterpret_cast<const f32x4 *>(p.gamma + n);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + wr * 128 + (mt >> 2) * 64 + (mt & 3) * 16 + l15;
+      if (m >= p.M) continue;
+      const f32x4 a = acc[mt][nt];
+      if (fast) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fn<ACT>(a[r] + bias4[r]) * gam4[r];
+        if (p.residual) v += *reinterpret_cast<const f32x4 *>(p.residual + (int64_t)m * p.ldr + n);
+        if (p.residual16) {
+          const half4 r16 = *reinterpret_cast<const half4 *>(p.residual16 + (int64_t)m * p.ldr16 + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r16[r];
+        }
+        if (p.out32) *reinterpret_cast<f32x4 *>(p.out32 + (int64_t)m * p.ldo32 + n) = v;
+        if (p.out16) {
+          half4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (h16)v[r];
+          *reinterpret_cast<half4 *>(p.out16 + (int64_t)m * p.ldo16 + n) = o;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nn = n + r;
+        if (nn >= p.N) {
+          if (nn < p.pad_to) p.out16[(int64_t)m * p.ldo16 + nn] = (h16)0.f;
+          continue;
+        }
+        const float b = p.bias ? p.bias[nn] : 0.f;
+        const float g = p.gamma ? p.gamma[nn] : 1.f;
+        float v = act_fn<ACT>(a[r] + b) * g;
+        if (p.residual) v += p.residual[(int64_t)m * p.ldr + nn];
+        if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + nn];
+        if (p.out32) p.out32[(int64_t)m * p.ldo32 + nn] = v;
+        if (p.out16) p.out16[(int64_t)m * p.ldo16 + nn] = (h16)v;
+      }
+    }
+  }
+#ifdef GSR_GEMM_TIMELINE
+  __syncthreads();
+  GEMM_STAMP(3);
+#endif
 }
 
 // ---- LayerNorm over the last dimension: one wave per row, fp32 statistics -------------------
@@ -993,6 +1547,13 @@ static inline unsigned grid_for(int64_t total) {
 
 using namespace gsr::dn;
 
+#ifdef GSR_GEMM_TIMELINE
+extern "C" int gsr_debug_set_gemm_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(gsr::dn::g_gemm_timeline), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 template <bool CONV>
 static int launch_gemm(const GemmArgs &p, void *stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -1010,7 +1571,38 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   // or many rounds. Measured: 4096^3 739 -> 950 TFLOP/s, 8192^3 800 -> 966, the 3349 x 4096 x 1024 MLP
   // GEMM (224 workgroups) 61 -> 54 us; 168 workgroups (QKV) or 56 (N = 1024) lose to the narrow tiles.
   const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
-  if (p.K >= 512 && ((b256 >= 192 && b256 <= 256) || b256 >= 768)) {
+  static const int force_core = getenv("GSR_DN_GEMM_CORE") ? atoi(getenv("GSR_DN_GEMM_CORE")) : 0;   // bench knob
+  // (gemm8p addresses its operands with 32-bit byte offsets)
+  const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32);
+  if (force_core == 4 && fits32) {
+    const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
+#define GSR_GEMM4(A) hipLaunchKernelGGL((gemm8p_kernel<A, CONV>), grid, dim3(512), 0, st, p)
+    switch (p.act) {
+      case ACT_GELU: GSR_GEMM4(ACT_GELU); break;
+      case ACT_RELU: GSR_GEMM4(ACT_RELU); break;
+      case ACT_SIGMOID: GSR_GEMM4(ACT_SIGMOID); break;
+      case ACT_TANH: GSR_GEMM4(ACT_TANH); break;
+      default: GSR_GEMM4(ACT_NONE); break;
+    }
+#undef GSR_GEMM4
+    GSR_CHECK_LAUNCH("dn_gemm8p");
+    return GSR_OK;
+  }
+  if (force_core == 3) {
+    const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
+#define GSR_GEMM3(A) hipLaunchKernelGGL((gemm_w128_kernel<A, CONV>), grid, dim3(256), 0, st, p)
+    switch (p.act) {
+      case ACT_GELU: GSR_GEMM3(ACT_GELU); break;
+      case ACT_RELU: GSR_GEMM3(ACT_RELU); break;
+      case ACT_SIGMOID: GSR_GEMM3(ACT_SIGMOID); break;
+      case ACT_TANH: GSR_GEMM3(ACT_TANH); break;
+      default: GSR_GEMM3(ACT_NONE); break;
+    }
+#undef GSR_GEMM3
+    GSR_CHECK_LAUNCH("dn_gemm_w128");
+    return GSR_OK;
+  }
+  if (force_core == 2 || (force_core == 0 && p.K >= 512 && ((b256 >= 192 && b256 <= 256) || b256 >= 768))) {
     const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
 #define GSR_GEMM2(A) hipLaunchKernelGGL((gemm256_kernel<A, CONV>), grid, dim3(512), 0, st, p)
     switch (p.act) {
