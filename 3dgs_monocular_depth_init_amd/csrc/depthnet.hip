@@ -253,204 +253,8 @@ gemm_kernel(GemmArgs p) {
     for (int j = 0; j < NJ; ++j) emit(acc[i][j], i, j);
 }
 
-// ---- 256x256x64 tile, two wave groups in ping-pong -----------------------------------------------
-// The 128-wide tiles above read as many LDS bytes per MFMA as the LDS can deliver (a 64x64 wave tile
-// needs 16 KB of fragments per 16 MFMAs: 1024 LDS cycles per CU against 1024 MFMA cycles per SIMD), so
-// they top out near 30 % of the MFMA peak. Here a wave owns 128x64 outputs (24 KB of fragments per
-// 32 MFMAs: ratio 0.75) and the eight waves of the workgroup run as two groups of four -- group g =
-// the upper / lower 128 rows, one wave of each group per SIMD -- offset by one barrier interval:
-// while one group issues its 32 MFMAs of a K-tile, the other reads the next K-tile's fragments from
-// LDS into registers, so neither the LDS latency nor the barrier is exposed to the matrix pipe.
-//   slot 2u   : group 0 LOAD(u) (+ issues the LDS-DMA of tile u+1) | group 1 MFMA(u-1) (+ DMA of tile u+1)
-//   slot 2u+1 : group 0 MFMA(u)                                   | group 1 LOAD(u)
-// Tile u lives in buffer u & 1. Its DMA is issued in slot 2u-2 (after the last reads of tile u-2, which
-// end with slot 2u-3), every wave waits for its own DMA (vmcnt(0)) before the barrier that ends slot
-// 2u-1, and the first read is in slot 2u: the wait-then-barrier order the LDS-DMA needs. Group 1 takes
-// one barrier more at the start, group 0 one more at the end: equal counts.
 constexpr int BM2 = 256, BN2 = 256;
-template <int ACT, bool CONV>
-__global__ void __launch_bounds__(512)
-gemm256_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM2 + BN2) * BK];   // 2 x 64 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave >> 2, wc = wave & 3;
-  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
-  int wg = blockIdx.y * nbx + blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
-    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
-  }
-  const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  // staging: wave w, instruction i moves rows (4w + i)*8 .. +7 of A and of B; lane -> (row, physical chunk)
-  const int srow = lane >> 3, pch = lane & 7;
-  const h16 *ga[4], *gb[4];
-  int pix_y[4], pix_x[4], lch[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + srow;
-    lch[i] = (pch ^ ((r >> 1) & 7)) * 8;
-    const int m = min(m0 + r, p.M - 1);
-    if (CONV) {
-      pix_y[i] = m / p.cW;
-      pix_x[i] = m - pix_y[i] * p.cW;
-      ga[i] = nullptr;
-    } else {
-      ga[i] = p.A + (int64_t)m * p.lda + lch[i];
-    }
-    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
-  }
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  auto stage = [&](int buf, int k0) {
-    int ky = 0, kx = 0, c0 = 0;
-    bool tap_ok = true;
-    if (CONV) {
-      const int tap = k0 / p.cC;
-      c0 = k0 - tap * p.cC;
-      ky = tap / p.cKS;
-      kx = tap - ky * p.cKS;
-      tap_ok = tap < p.cKS * p.cKS;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const h16 *src;
-      if (CONV) {
-        const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
-        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
-      } else {
-        src = ga[i] + k0;
-      }
-      h16 *dA = &smem[buf][(wave * 4 + i) * 8 * BK];
-      h16 *dB = &smem[buf][BM2 * BK + (wave * 4 + i) * 8 * BK];
-      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dA, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + k0), (lds_void *)dB, 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  half8 af[4][4], bf[2][4];   // [tile][k-step]
-
-  auto load_frags = [&](int buf) {
-    const h16 *sA = smem[buf], *sB = smem[buf] + BM2 * BK;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int cl = 2 * s + lh;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = grp * 128 + i * 32 + lr;
-        af[i][s] = *reinterpret_cast<const half8 *>(sA + ra * BK + ((cl ^ ((ra >> 1) & 7)) << 3));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int rb = wc * 64 + j * 32 + lr;
-        bf[j][s] = *reinterpret_cast<const half8 *>(sB + rb * BK + ((cl ^ ((rb >> 1) & 7)) << 3));
-      }
-    }
-  };
-  auto mfma_tile = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-#define GSR_SLOT_END()                              \
-  __builtin_amdgcn_sched_barrier(0);                \
-  __builtin_amdgcn_s_barrier();                     \
-  __builtin_amdgcn_sched_barrier(0)
-#define GSR_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define GSR_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  GSR_WAIT_DMA();
-  GSR_SLOT_END();                                  // tile 0 is in LDS for everyone
-  if (grp == 0) {
-    for (int u = 0; u < nk; ++u) {
-      if (u + 1 < nk) stage((u + 1) & 1, (u + 1) * BK);     // slot 2u: LOAD(u)
-      load_frags(u & 1);
-      GSR_WAIT_LDS();
-      GSR_SLOT_END();
-      mfma_tile();                                           // slot 2u+1: MFMA(u)
-      GSR_WAIT_DMA();
-      GSR_SLOT_END();
-    }
-    GSR_SLOT_END();                                          // (group 1's last MFMA slot)
-  } else {
-    if (1 < nk) stage(1, BK);                                // slot 0: this group's share of tile 1
-    GSR_SLOT_END();
-    for (int u = 0; u < nk; ++u) {
-      load_frags(u & 1);                                     // slot 2u+1: LOAD(u)
-      GSR_WAIT_LDS();
-      GSR_WAIT_DMA();
-      GSR_SLOT_END();
-      if (u + 2 < nk) stage(u & 1, (u + 2) * BK);            // slot 2u+2: MFMA(u), DMA of tile u+2
-      mfma_tile();
-      GSR_SLOT_END();
-    }
-  }
-#undef GSR_SLOT_END
-#undef GSR_WAIT_DMA
-#undef GSR_WAIT_LDS
-
-  // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 64 + j * 32 + lr;
-      const int mb = m0 + grp * 128 + i * 32 + 4 * lh;
-      if (n >= p.N) {
-        if (n < p.pad_to) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            if (m < p.M) p.out16[(int64_t)m * p.ldo16 + n] = (h16)0.f;
-          }
-        }
-        continue;
-      }
-      const float b = p.bias ? p.bias[n] : 0.f;
-      const float g = p.gamma ? p.gamma[n] : 1.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= p.M) continue;
-        float v = act_fn<ACT>(acc[i][j][r] + b) * g;
-        if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
-        if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
-        if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
-        if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
-      }
-    }
-}
-
-// ---- 256x256x64 tile, FOUR waves of 128x128 outputs, one wave per SIMD ------------------------------
-// The step beyond the ping-pong kernel above: a 128x128 wave tile needs 8 fragment reads (8 KB) per 16
-// MFMAs -- 32 KB of LDS reads per K-step and CU (256 LDS cycles) against 512 MFMA cycles per SIMD, plus
-// the LDS-DMA writes of the next tile (another 128 cycles per K-step): the LDS pipe is at 75 % when the
-// matrix pipe is full, so the matrix pipe is what bounds it. With one wave per SIMD nothing hides a
-// wave's own latencies, so the wave is software-pipelined by hand:
-//   * fragments double-buffered in registers: K-step s issues the reads of step s+1, then its 16 MFMAs;
-//   * ONE barrier per K-tile, between K-steps 2 and 3: by then the wave has read all of tile u, and it
-//     has waited for its own DMA of tile u+1 (issued a whole tile earlier); after the barrier tile u+1
-//     is complete for everyone and tile u's buffer is free, so the DMA of tile u+2 is issued into it
-//     and K-step 3 reads step 0 of tile u+1 under its MFMAs. The matrix pipe only sees the barrier skew.
-// The DMAs are asm statements (raster_common.h: the compiler would otherwise drain them before the
-// next LDS read). Accumulators: 16 tiles x 16 = 256 registers (AGPRs), ~110 VGPRs beside them.
+// LDS-DMA as asm statements (raster_common.h explains why): destination = wave-uniform LDS byte address
 __device__ __forceinline__ void dn_dma_16B(const void *src_lane, uint32_t lds_dst_uniform) {
   unsigned keep;
   asm volatile(
@@ -468,179 +272,6 @@ __device__ __forceinline__ void dn_dma_16B_off(const void *base_uniform, uint32_
       : "v"(byte_off_lane), "s"(base_uniform), "s"(lds_dst_uniform)
       : "memory");
 }
-template <int ACT, bool CONV>
-__global__ void __launch_bounds__(256)
-gemm_w128_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM2 + BN2) * BK];   // 2 x 64 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nbx = gridDim.x, nby = gridDim.y, nwg = nbx * nby;
-  int wg = blockIdx.y * nbx + blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
-    wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
-  }
-  const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  // staging: wave w, instruction i moves rows (8w + i)*8 .. +7 of A and of B; lane -> (row, physical chunk)
-  const int srow = lane >> 3, pch = lane & 7;
-  const h16 *ga[8], *gb[8];
-  int pix_y[8], pix_x[8], lch[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = (wave * 8 + i) * 8 + srow;
-    lch[i] = (pch ^ ((r >> 1) & 7)) * 8;
-    const int m = min(m0 + r, p.M - 1);
-    if (CONV) {
-      pix_y[i] = m / p.cW;
-      pix_x[i] = m - pix_y[i] * p.cW;
-      ga[i] = nullptr;
-    } else {
-      ga[i] = p.A + (int64_t)m * p.lda + lch[i];
-    }
-    gb[i] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.K + lch[i];
-  }
-  typedef __attribute__((address_space(3))) void lds_void;
-  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_void *)&smem[0][0]);
-  auto stage = [&](int buf, int k0) {
-    int ky = 0, kx = 0, c0 = 0;
-    bool tap_ok = true;
-    if (CONV) {
-      const int tap = k0 / p.cC;
-      c0 = k0 - tap * p.cC;
-      ky = tap / p.cKS;
-      kx = tap - ky * p.cKS;
-      tap_ok = tap < p.cKS * p.cKS;
-    }
-    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(lds0 + (uint32_t)buf * (uint32_t)((BM2 + BN2) * BK * 2) + (uint32_t)wave * (64 * BK * 2)));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const h16 *src;
-      if (CONV) {
-        const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
-        const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
-      } else {
-        src = ga[i] + k0;
-      }
-      dn_dma_16B(src, base + (uint32_t)i * (8 * BK * 2));
-      dn_dma_16B(gb[i] + k0, base + (uint32_t)(BM2 * BK * 2) + (uint32_t)i * (8 * BK * 2));
-    }
-  };
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  half8 fa[2][4], fb[2][4];   // [register buffer][tile]
-
-  const int swz = (lr >> 1) & 7;
-  auto read_frags = [&](int buf, int s, int rb) {
-    const h16 *sA = smem[buf] + (wm * 128 + lr) * BK, *sB = smem[buf] + BM2 * BK + (wn * 128 + lr) * BK;
-    const int c = ((2 * s + lh) ^ swz) << 3;
-#if defined(GSR_W128_KO) && GSR_W128_KO == 3
-    if (p.M != 12345) return;     // knock-out: no fragment reads (registers keep whatever they hold)
-#endif
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fa[rb][t] = *reinterpret_cast<const half8 *>(sA + t * 32 * BK + c);
-      fb[rb][t] = *reinterpret_cast<const half8 *>(sB + t * 32 * BK + c);
-    }
-  };
-  auto mfma_step = [&](int rb) {
-#if defined(GSR_W128_KO) && GSR_W128_KO == 2
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i], fb[rb][i], acc[i][i], 0, 0, 0);
-    for (int i = 0; i < 3; ++i) acc[i][i + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i + 1], fb[rb][i], acc[i][i + 1], 0, 0, 0);
-#else
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[rb][i], fb[rb][j], acc[i][j], 0, 0, 0);
-#endif
-  };
-  // 8 fragment reads spread under 16 MFMAs
-#define GSR_INTERLEAVE()                                   \
-  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {       \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     \
-  }
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  if (nk > 1) {
-    stage(1, BK);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 landed (tile 1's 16 DMAs may be in flight)
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  read_frags(0, 0, 0);
-  for (int u = 0; u < nk; ++u) {
-    const int buf = u & 1;
-    read_frags(buf, 1, 1);
-    mfma_step(0);
-    GSR_INTERLEAVE();
-    read_frags(buf, 2, 0);
-    mfma_step(1);
-    GSR_INTERLEAVE();
-    read_frags(buf, 3, 1);
-    mfma_step(0);
-    GSR_INTERLEAVE();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#if !defined(GSR_W128_KO) || GSR_W128_KO != 1
-    if (u + 2 < nk) stage(buf, (u + 2) * BK);
-#endif
-    if (u + 1 < nk) read_frags(buf ^ 1, 0, 0);
-    mfma_step(1);
-    GSR_INTERLEAVE();
-  }
-#undef GSR_INTERLEAVE
-
-  // epilogue: lane holds column n, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5) of each 32x32 tile
-  auto emit = [&](const f32x16 &a, int i, int j) {
-    const int n = n0 + wn * 128 + j * 32 + lr;
-    const int mb = m0 + wm * 128 + i * 32 + 4 * lh;
-    if (n >= p.N) {
-      if (n < p.pad_to) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) p.out16[(int64_t)m * p.ldo16 + n] = (h16)0.f;
-        }
-      }
-      return;
-    }
-    const float b = p.bias ? p.bias[n] : 0.f;
-    const float g = p.gamma ? p.gamma[n] : 1.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mb + (r & 3) + 8 * (r >> 2);
-      if (m >= p.M) continue;
-      float v = act_fn<ACT>(a[r] + b) * g;
-      if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
-      if (p.residual16) v += (float)p.residual16[(int64_t)m * p.ldr16 + n];
-      if (p.out32) p.out32[(int64_t)m * p.ldo32 + n] = v;
-      if (p.out16) p.out16[(int64_t)m * p.ldo16 + n] = (h16)v;
-    }
-  };
-#define GSR_EMIT_ROW(I) emit(acc[I][0], I, 0); emit(acc[I][1], I, 1); emit(acc[I][2], I, 2); emit(acc[I][3], I, 3)
-  GSR_EMIT_ROW(0);
-  GSR_EMIT_ROW(1);
-  GSR_EMIT_ROW(2);
-  GSR_EMIT_ROW(3);
-#undef GSR_EMIT_ROW
-}
-
 // ---- 256x256x64 tile in eight phases per two K-tiles (the guide's verified structure, section 5) -------
 // Eight waves as 2 (rows) x 4 (columns), 128x64 outputs each, v_mfma_f32_16x16x32_f16. A K-tile is
 // staged as FOUR half-tiles of 16 KB -- A0 / A1 = the upper / lower 64 rows of each wave row's 128,
@@ -689,6 +320,7 @@ gemm8p_kernel(GemmArgs p) {
     wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
   }
   const int m0 = (wg / nbx) * BM2, n0 = (wg % nbx) * BN2;
+  const int nk = p.K / BK, NQ = 4 * nk;
 
   // staging: a half-tile is 16 units of 8 rows; wave w moves units 2w and 2w+1. lane -> (row, physical chunk).
   // local row r of an A half h is tile row (r >> 6) * 128 + h * 64 + (r & 63); of a B half h it is
@@ -795,7 +427,6 @@ gemm8p_kernel(GemmArgs p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
   GSR_BAR()
 
-  const int nk = p.K / BK, NQ = 4 * nk;
   // prologue: half-tiles 0..6 in flight, tile 0 waited for
 #pragma unroll
   for (int q = 0; q < 7; ++q)
@@ -988,6 +619,61 @@ gemm8p_kernel(GemmArgs p) {
   __syncthreads();
   GEMM_STAMP(3);
 #endif
+}
+
+// ---- 3x3 convolution with a handful of output channels, accumulated into an fp32 field -------------
+// The flow head's last layers (RAFTDepthNormalDPTDecoder5.py:282-297): 128 -> 2 and 128 -> 4 channels at
+// 1/4 resolution, added to the fp32 flow field, eight times per image. As im2col rows + GEMM that is a
+// 94 MB buffer written and read for 0.4 GFLOP (25 + 40 us per head and iteration); here sixteen lanes
+// share a pixel -- lane = (pixel of 4, 8-channel chunk of 16) -- read the nine taps straight from the map,
+// take their dot products with the weights (staged once per workgroup in LDS), and a 4-step lane
+// reduction leaves the N sums: the map is read once from memory (taps hit the caches), nothing is written
+// but the N values.
+constexpr int HEAD_MAX_N = 8;
+template <int N>
+__global__ void __launch_bounds__(256)
+conv3_head_kernel(int H, int W, int C, const h16 *__restrict__ in, int ldi, const h16 *__restrict__ wt,
+                  int K_pad, const float *__restrict__ bias, float *__restrict__ out, int ldo) {
+  extern __shared__ h16 sW[];                       // [N][9 * C]
+  const int K = 9 * C;
+  for (int i = threadIdx.x * 8; i < N * K; i += 256 * 8) {
+    const int n = i / K, k = i - n * K;
+    *reinterpret_cast<half8 *>(sW + i) = *reinterpret_cast<const half8 *>(wt + (int64_t)n * K_pad + k);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, chunk = lane & 15, sub = lane >> 4;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  const int P = H * W;
+  for (int p0 = wave * 4; p0 < P; p0 += nwaves * 4) {
+    const int pix = min(p0 + sub, P - 1);
+    const int y = pix / W, x = pix - y * W;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int c0 = chunk * 8; c0 < C; c0 += 128) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const half8 v = *reinterpret_cast<const half8 *>(in + ((int64_t)iy * W + ix) * ldi + c0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          const half8 w = *reinterpret_cast<const half8 *>(sW + n * K + tap * C + c0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[n] = fmaf((float)v[e], (float)w[e], acc[n]);
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) acc[n] += __shfl_xor(acc[n], m, 64);
+    }
+    if (chunk == 0 && p0 + sub < P) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) out[(int64_t)pix * ldo + n] += acc[n] + (bias ? bias[n] : 0.f);
+    }
+  }
 }
 
 // ---- LayerNorm over the last dimension: one wave per row, fp32 statistics -------------------
@@ -1567,14 +1253,16 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   const int b128 = rows * gsr::ceil_div(p.N, 128), b64 = rows * gsr::ceil_div(p.N, 64);
   // (only where the rounding matters, up to two rounds: 8192^3 is 1390 us wide, 1560 us narrow)
   const bool narrow = p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512);
-  // 256x256 ping-pong tile where its grid fills the chip: one round of 192..256 workgroups (one per CU),
-  // or many rounds. Measured: 4096^3 739 -> 950 TFLOP/s, 8192^3 800 -> 966, the 3349 x 4096 x 1024 MLP
-  // GEMM (224 workgroups) 61 -> 54 us; 168 workgroups (QKV) or 56 (N = 1024) lose to the narrow tiles.
+  // The 256x256 eight-phase core wherever its grid occupies the chip: from 112 workgroups (one round on
+  // 256 CUs) up. Same box, plain fp16 GEMM, TFLOP/s (profiles/r03_depthnet_gemm.md): 3349x3072x1024
+  // 459 -> 679, 3349x4096x1024 495 -> 860, 40964x256x2304 582 -> 811, 40964x512x2880 666 -> 908,
+  // 4096^3 943 -> 1279; with 56-106 workgroups (N = 1024 at 3349 rows, the 1/7 and 1/14 maps) the
+  // 128-row tiles below stay ahead. GSR_DN_GEMM_CORE=1 / 4 forces a core (bench knob).
+  static const int force_core = getenv("GSR_DN_GEMM_CORE") ? atoi(getenv("GSR_DN_GEMM_CORE")) : 0;
   const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
-  static const int force_core = getenv("GSR_DN_GEMM_CORE") ? atoi(getenv("GSR_DN_GEMM_CORE")) : 0;   // bench knob
   // (gemm8p addresses its operands with 32-bit byte offsets)
   const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32);
-  if (force_core == 4 && fits32) {
+  if (fits32 && (force_core == 4 || (force_core == 0 && p.K >= 256 && b256 >= 112))) {
     const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
 #define GSR_GEMM4(A) hipLaunchKernelGGL((gemm8p_kernel<A, CONV>), grid, dim3(512), 0, st, p)
     switch (p.act) {
@@ -1586,34 +1274,6 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
     }
 #undef GSR_GEMM4
     GSR_CHECK_LAUNCH("dn_gemm8p");
-    return GSR_OK;
-  }
-  if (force_core == 3) {
-    const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
-#define GSR_GEMM3(A) hipLaunchKernelGGL((gemm_w128_kernel<A, CONV>), grid, dim3(256), 0, st, p)
-    switch (p.act) {
-      case ACT_GELU: GSR_GEMM3(ACT_GELU); break;
-      case ACT_RELU: GSR_GEMM3(ACT_RELU); break;
-      case ACT_SIGMOID: GSR_GEMM3(ACT_SIGMOID); break;
-      case ACT_TANH: GSR_GEMM3(ACT_TANH); break;
-      default: GSR_GEMM3(ACT_NONE); break;
-    }
-#undef GSR_GEMM3
-    GSR_CHECK_LAUNCH("dn_gemm_w128");
-    return GSR_OK;
-  }
-  if (force_core == 2 || (force_core == 0 && p.K >= 512 && ((b256 >= 192 && b256 <= 256) || b256 >= 768))) {
-    const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
-#define GSR_GEMM2(A) hipLaunchKernelGGL((gemm256_kernel<A, CONV>), grid, dim3(512), 0, st, p)
-    switch (p.act) {
-      case ACT_GELU: GSR_GEMM2(ACT_GELU); break;
-      case ACT_RELU: GSR_GEMM2(ACT_RELU); break;
-      case ACT_SIGMOID: GSR_GEMM2(ACT_SIGMOID); break;
-      case ACT_TANH: GSR_GEMM2(ACT_TANH); break;
-      default: GSR_GEMM2(ACT_NONE); break;
-    }
-#undef GSR_GEMM2
-    GSR_CHECK_LAUNCH("dn_gemm256");
     return GSR_OK;
   }
 #define GSR_GEMM(A, BNT_)                                                                             \
@@ -1751,6 +1411,29 @@ extern "C" int gsr_dn_im2col(int H, int W, int C, int ldi, int KS, int stride, i
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, H, W, C, ldi,
                      KS, stride, pad, Ho, Wo, K_pad, (const h16 *)in, (h16 *)rows, relu);
   GSR_CHECK_LAUNCH("dn_im2col");
+  return GSR_OK;
+}
+
+extern "C" int gsr_dn_conv3_head(int H, int W, int C, const void *in, int ldi, int N, const void *Wt, int K_pad,
+                                 const float *bias, float *out32, int ldo, void *stream) {
+  GSR_REQUIRE(H > 0 && W > 0 && C > 0 && C % 8 == 0 && N >= 1 && N <= gsr::dn::HEAD_MAX_N && K_pad >= 9 * C && ldo >= N,
+              "dn_conv3_head: bad sizes H=%d W=%d C=%d N=%d K_pad=%d ldo=%d", H, W, C, N, K_pad, ldo);
+  GSR_REQUIRE(in && Wt && out32, "dn_conv3_head: null pointer");
+  GSR_REQUIRE((ldi & 7) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)Wt & 15) == 0 && (K_pad & 7) == 0,
+              "dn_conv3_head: rows of the map and of the weights must be 16-byte aligned");
+  const size_t lds = (size_t)N * 9 * C * sizeof(h16);
+  GSR_REQUIRE(lds <= 64 * 1024, "dn_conv3_head: %d x 9 x %d weights do not fit the LDS staging", N, C);
+  const int64_t P = (int64_t)H * W;
+  int grid = (int)gsr::ceil_div64(P, 16 * 4);            // four pixel groups per wave and trip, ~4 trips
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+#define GSR_HEAD(N_) case N_: hipLaunchKernelGGL((conv3_head_kernel<N_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, \
+                                                 H, W, C, (const h16 *)in, ldi, (const h16 *)Wt, K_pad, bias, out32, ldo); break
+  switch (N) {
+    GSR_HEAD(1); GSR_HEAD(2); GSR_HEAD(3); GSR_HEAD(4); GSR_HEAD(5); GSR_HEAD(6); GSR_HEAD(7); GSR_HEAD(8);
+  }
+#undef GSR_HEAD
+  GSR_CHECK_LAUNCH("dn_conv3_head");
   return GSR_OK;
 }
 

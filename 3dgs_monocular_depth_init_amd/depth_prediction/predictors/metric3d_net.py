@@ -508,11 +508,18 @@ class Metric3DNet:
             self._gru("gru08", nets[0], ctxs[0], [flow_in, up1])
             # flow head (:282-297): [conv1d | conv1n] in one GEMM, then the two 3x3 output convs
             f1 = self.conv(nets[0], self.fh1, 3, Map(H4, W4, 2 * C2, dev, zero=False), act=ACT_RELU)
-            rows = self._buf("fh_rows", (P4, self.fh2d.kp))
             if return_intermediates:
                 before = flow.clone()
             for lin, c0, o0, no in ((self.fh2d, 0, 0, 2), (self.fh2n, C2, 2, 4)):
                 part = f1.chan(c0, C2)
+                if C2 % 8 == 0 and part.t.data_ptr() % 16 == 0 and lin.k == 9 * C2 and 9 * C2 * no * 2 <= 65536:
+                    # the 2 / 4 output channels straight from the map, added to the fp32 flow field
+                    if self.flop_count is not None:
+                        self.flop_count += 2.0 * P4 * no * lin.k
+                    call("gsr_dn_conv3_head", H4, W4, C2, ptr(part.t), part.ld, no, ptr(lin.w), lin.kp, ptr(lin.b),
+                         ptr(flow[:, o0:]), 6, _st())
+                    continue
+                rows = self._buf("fh_rows", (P4, lin.kp))
                 call("gsr_dn_im2col", H4, W4, C2, part.ld, 3, 1, 1, H4, W4, lin.kp, ptr(part.t), ptr(rows), 0, _st())
                 self.gemm(P4, lin, rows, lin.kp, residual=flow[:, o0:], ldr=6, out32=flow[:, o0:], ldo32=6)
             if return_intermediates:

@@ -524,7 +524,8 @@ int gsr_m3d_postprocess(int in_h, int in_w, const float *in, int pad_top, int pa
  * rows = tokens or pixels (NHWC maps), weights [N, K] as nn.Linear / flattened conv weights
  * with K padded to a multiple of 64 by zeros.
  * --------------------------------------------------------------------------*/
-/* out = residual + gamma * act(A[M,K] W[N,K]^T + bias): v_mfma_f32_32x32x16_f16, fp32 accumulate.
+/* out = residual + gamma * act(A[M,K] W[N,K]^T + bias): fp16 MFMA (v_mfma_f32_16x16x32_f16 in the
+ * 256x256 eight-phase core, v_mfma_f32_32x32x16_f16 in the 128-row tiles), fp32 accumulate.
  * act: 0 none, 1 GELU(erf), 2 ReLU, 3 sigmoid, 4 tanh. bias/gamma [N] fp32 or NULL; residual
  * fp32 [M,ldr] and/or residual16 fp16 [M,ldr16] or NULL (may alias the outputs); out16 and/or
  * out32 receive the result. K % 64 == 0, lda >= K, lda % 8 == 0. out16_pad_to: 0, or the number of
@@ -539,6 +540,12 @@ int gsr_dn_gemm(int M, int N, int K, const void *A, int lda, const void *W, cons
 int gsr_dn_conv_gemm(int H, int W, int C, const void *in, int ldi, int KS, int N, int K_pad,
                      const void *Wt, const float *bias, int act, const void *residual16, int ldr16,
                      void *out16, int ldo16, const void *zero_page, int out16_pad_to, void *stream);
+/* out32[p, 0:N] += bias + conv3x3(in)[p, 0:N] for N <= 8 output channels (stride 1, "same" padding): the
+ * flow head's last layers (RAFTDepthNormalDPTDecoder5.py:282-297), which add 2 / 4 channels to the
+ * fp32 flow field. in: NHWC fp16 map [H*W, ldi] with C % 8 == 0 channels; Wt [N, K_pad] fp16 in im2col
+ * column order (tap * C + c); no im2col buffer, no GEMM tile of which 2 columns are used. */
+int gsr_dn_conv3_head(int H, int W, int C, const void *in, int ldi, int N, const void *Wt, int K_pad,
+                      const float *bias, float *out32, int ldo, void *stream);
 /* LayerNorm over the last dimension of [M,D] (fp32 or fp16 input), optional ReLU. */
 int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,
                      const float *beta, float eps, void *out16, int ldo16, float *out32, int ldo32,

@@ -50,8 +50,9 @@ def _gemm(N, A, W, bias=None, act=0, gamma=None, residual=None, out32=True):
     return o16, o32
 
 
-# (3349, 4096, 1024) and (3900, 3900, 576) take the 256x256 ping-pong kernel (224 / 256 workgroups, ragged
-# edges in M and N, odd and even K-tile counts), the others the 128-row tiles in both widths
+# (3349, 4096, 1024), (3900, 3900, 576) and (40964, 256, 2304) take the 256x256 eight-phase core (224 / 256 /
+# 161 workgroups, ragged edges in M and N, odd and even K-tile counts), the others the 128-row tiles in
+# both widths
 @pytest.mark.parametrize("M,n,K", [(3349, 1152, 384), (3349, 1024, 4096), (1, 384, 1920), (200, 258, 512),
                                    (40964, 256, 2304), (130, 6, 448), (3349, 4096, 1024), (3900, 3900, 576)])
 def test_gemm_vs_torch(N, M, n, K):
@@ -82,6 +83,58 @@ def test_gemm_epilogues_vs_torch(N):
     lib.call("gsr_dn_gemm", M, n, K, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), 0, gamma.data_ptr(),
              r.data_ptr(), n, None, 0, None, 0, r.data_ptr(), n, 0, _st())    # x += gamma * (A W^T + b), in place
     assert torch.allclose(r, res + gamma * z, rtol=2e-5, atol=2e-5)
+
+
+def test_gemm_eight_phase_core_epilogues_vs_torch(N):
+    """The 256x256 core (grid of 12 x 12 tiles) with every epilogue input: rows through LDS where a wave's
+    64 columns are inside N, element-wise at the ragged right edge; GELU, LayerScale, fp32 residual in
+    place, fp16 residual, fp16 output with zero channels up to the padded width; 5 K-tiles (odd)."""
+    lib = mod("_lib")
+    g = torch.Generator().manual_seed(11)
+    M, n, K = 3000, 2968, 320
+    A = torch.randn(M, K, generator=g).half().cuda()
+    W = (torch.randn(n, K, generator=g) / K ** 0.5).half().cuda()
+    bias, gamma = torch.randn(n, generator=g).cuda(), torch.rand(n, generator=g).cuda()
+    res = torch.randn(M, n, generator=g).cuda()
+    z = A.float() @ W.float().T + bias
+    o16, o32 = _gemm(N, A, W, bias, act=1)
+    assert torch.allclose(o32, F.gelu(z), rtol=2e-5, atol=3e-5)
+    assert float((o16.float() - F.gelu(z)).abs().max()) <= 1.5e-3 * float(z.abs().max())
+    r = res.clone()
+    lib.call("gsr_dn_gemm", M, n, K, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), 0, gamma.data_ptr(),
+             r.data_ptr(), n, None, 0, None, 0, r.data_ptr(), n, 0, _st())    # x += gamma * (A W^T + b), in place
+    assert torch.allclose(r, res + gamma * z, rtol=2e-5, atol=3e-5)
+    ld = 3008                                                                 # the map's stored width (n -> 64)
+    r16 = torch.randn(M, ld, generator=g).half().cuda()
+    out = torch.full((M, ld), 7.0, dtype=torch.float16, device="cuda")
+    lib.call("gsr_dn_gemm", M, n, K, A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), 2, None, None, 0,
+             r16.data_ptr(), ld, out.data_ptr(), ld, None, 0, ld, _st())
+    ref = torch.relu(z) + r16[:, :n].float()
+    assert float((out[:, :n].float() - ref).abs().max()) <= 1.5e-3 * float(ref.abs().max())
+    assert float(out[:, n:].abs().max()) == 0.0                               # zero channels written
+
+
+def test_conv3_head_vs_torch(N):
+    """gsr_dn_conv3_head: flow[:, o:o+n] += bias + conv3x3(map)[:, :n] for the flow head's 2- and
+    4-channel outputs, against F.conv2d in fp32 on the same fp16 operands."""
+    lib = mod("_lib")
+    g = torch.Generator().manual_seed(3)
+    H, Wd, C, ld = 37, 53, 128, 256
+    full = torch.randn(H * Wd, ld, generator=g).half().cuda()
+    for c0, o0, n in ((0, 0, 2), (128, 2, 4)):
+        w = (torch.randn(n, C, 3, 3, generator=g) / (9 * C) ** 0.5).half()
+        b = torch.randn(n, generator=g).cuda()
+        rows = w.permute(0, 2, 3, 1).reshape(n, 9 * C).contiguous().cuda()     # column = (ky * 3 + kx) * C + c
+        flow = torch.randn(H * Wd, 6, generator=g).cuda()
+        before = flow.clone()
+        part = full[:, c0:]
+        lib.call("gsr_dn_conv3_head", H, Wd, C, part.data_ptr(), ld, n, rows.data_ptr(), 9 * C, b.data_ptr(),
+                 flow[:, o0:].data_ptr(), 6, _st())
+        x = full[:, c0:c0 + C].float().reshape(1, H, Wd, C).permute(0, 3, 1, 2)
+        ref = F.conv2d(x, w.float().cuda(), b, padding=1)[0].permute(1, 2, 0).reshape(H * Wd, n)
+        assert torch.allclose(flow[:, o0:o0 + n], before[:, o0:o0 + n] + ref, rtol=1e-4, atol=1e-4)
+        keep = [c for c in range(6) if not (o0 <= c < o0 + n)]
+        assert torch.equal(flow[:, keep], before[:, keep])                      # the other columns untouched
 
 
 # key split of the workgroup (gsr_dn_attention): (101, 2) and (1500, 64) run unsplit, (3349, 16) in two groups,
