@@ -419,6 +419,31 @@ extern "C" int gsr_relocation(int n, const float *opacities, const float *scales
   return GSR_OK;
 }
 
+namespace gsr {
+// gsplat.strategy.ops.reset_opa (DefaultStrategy every reset_every steps, runner.py:639-647): logit
+// opacities clamped from above, the opacity optimizer's two moments cleared -- one pass, in place.
+__global__ void __launch_bounds__(256)
+reset_opacity_kernel(int64_t n, float *__restrict__ logit_opac, float *__restrict__ exp_avg,
+                     float *__restrict__ exp_avg_sq, float max_logit) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  logit_opac[i] = fminf(logit_opac[i], max_logit);
+  if (exp_avg) exp_avg[i] = 0.f;
+  if (exp_avg_sq) exp_avg_sq[i] = 0.f;
+}
+}  // namespace gsr
+
+extern "C" int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_avg, float *exp_avg_sq,
+                                 float max_logit, void *stream) {
+  GSR_REQUIRE(n >= 0, "reset_opacity: bad n");
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(logit_opacities, "reset_opacity: null pointer");
+  hipLaunchKernelGGL(gsr::reset_opacity_kernel, dim3((unsigned)gsr::ceil_div64(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, logit_opacities, exp_avg, exp_avg_sq, max_logit);
+  GSR_CHECK_LAUNCH("reset_opacity");
+  return GSR_OK;
+}
+
 extern "C" int gsr_inject_noise(int N, float *means, const float *quats, const float *log_scales,
                                 const float *logit_opacities, const float *noise, float scaler,
                                 void *stream) {

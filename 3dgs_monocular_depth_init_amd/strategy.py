@@ -122,9 +122,79 @@ def remove(params, optimizers, state: Dict[str, Tensor], mask: Tensor) -> None:
 
 @torch.no_grad()
 def reset_opa(params, optimizers, state: Dict[str, Tensor], value: float) -> None:
+    max_logit = math.log(value / (1.0 - value))
+    p = params["opacities"]
+    if p.is_cuda and p.is_contiguous() and p.dtype == torch.float32:
+        # in place, one launch: the clamp and the two moments (gsr_reset_opacity)
+        stt = _opt_of(optimizers, "opacities").state.get(p, {})
+        m, v = stt.get("exp_avg"), stt.get("exp_avg_sq")
+        if all(t is None or (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel()) for t in (m, v)):
+            from ._lib import ptr
+            _call()("gsr_reset_opacity", p.numel(), ptr(p.detach()), ptr(m), ptr(v), float(max_logit),
+                    torch.cuda.current_stream().cuda_stream)
+            return
     _update_param_with_optimizer(
-        lambda n, p: torch.clamp(p, max=math.log(value / (1.0 - value))),
+        lambda n, p: torch.clamp(p, max=max_logit),
         lambda k, v: torch.zeros_like(v), params, optimizers, names=["opacities"])
+
+
+@torch.no_grad()
+def _rebuild_by_gather(params, optimizers, M: int, src: Tensor, kind: Tensor,
+                       src_m: Optional[Tensor] = None, kind_m: Optional[Tensor] = None) -> None:
+    """Every parameter and both of its Adam moments rebuilt with M rows by `gsr_refine_gather` (the
+    multi-tensor row gather of the one-pass refine step): parameter rows new[r] = old[src[r]]; moment
+    rows new[r] = old[src_m[r]], or zero where kind_m[r] != 0 (src_m / kind_m default to src / kind).
+    Then the tensors are handed to the parameter dict and the optimizers as
+    `_update_param_with_optimizer` does."""
+    import ctypes as C
+
+    from ._lib import ptr
+    call = _call()
+    dev = src.device
+    st = torch.cuda.current_stream().cuda_stream
+    src_m = src if src_m is None else src_m
+    kind_m = kind if kind_m is None else kind_m
+    N = len(next(iter(params.values())))
+    p_jobs, m_jobs, new_params, new_moments = [], [], {}, {}
+    for name, p in params.items():
+        old = p.detach()
+        if not (old.is_contiguous() and old.dtype == torch.float32):
+            raise ValueError(f"rebuild: parameter {name!r} must be contiguous fp32")
+        L = max(1, int(old.numel() // max(N, 1)))
+        new_params[name] = torch.empty((M, *old.shape[1:]), dtype=torch.float32, device=dev)
+        p_jobs.append((old, new_params[name], L, 0))
+        for k, v in _opt_of(optimizers, name).state.get(p, {}).items():
+            if k != "step":
+                nv = torch.empty((M, *v.shape[1:]), dtype=torch.float32, device=dev)
+                new_moments[(name, k)] = nv
+                m_jobs.append((v.contiguous(), nv, L, 1))
+    if M > 0 and N > 0:
+        for jobs, s_, k_ in ((p_jobs, src, kind), (m_jobs, src_m, kind_m)):
+            for a in range(0, len(jobs), 24):
+                part = jobs[a:a + 24]
+                n = len(part)
+                PA, IA = C.c_void_p * n, C.c_int32 * n
+                call("gsr_refine_gather", n, M, ptr(s_), ptr(k_), PA(*[ptr(j[0]) for j in part]),
+                     PA(*[ptr(j[1]) for j in part]), IA(*[j[2] for j in part]), IA(*[j[3] for j in part]), st)
+    for name in list(params.keys()):
+        old = params[name]
+        new = torch.nn.Parameter(new_params[name], requires_grad=old.requires_grad)
+        opt = _opt_of(optimizers, name)
+        for g in opt.param_groups:
+            for i, p in enumerate(g["params"]):
+                if p is old:
+                    stt = opt.state.pop(p, {})
+                    for k in list(stt.keys()):
+                        if k != "step":
+                            stt[k] = new_moments[(name, k)]
+                    g["params"][i] = new
+                    if stt:
+                        opt.state[new] = stt
+        params[name] = new
+
+
+def _gather_ok(params) -> bool:
+    return all(p.is_cuda and p.is_contiguous() and p.dtype == torch.float32 for p in params.values())
 
 
 @dataclass
@@ -447,6 +517,28 @@ def relocate(params, optimizers, state, mask: Tensor, binoms: Tensor, min_opacit
         opacities[sampled], torch.exp(params["scales"])[sampled],
         torch.bincount(sampled, minlength=len(opacities))[sampled] + 1, binoms)
     new_o = torch.clamp(new_o, max=1.0 - eps, min=min_opacity)
+    if _gather_ok(params):
+        # one gather for the parameters (dead rows take their sampled row), one for the Adam moments
+        # (rows kept, zero at the sampled rows), then the new opacity / scale of the sampled rows and of
+        # their copies
+        N = len(opacities)
+        dev = opacities.device
+        src = torch.arange(N, dtype=torch.int32, device=dev)
+        src[dead] = sampled.int()
+        kind = torch.zeros(N, dtype=torch.uint8, device=dev)
+        kind_m = kind.clone()
+        kind_m[sampled] = 1
+        _rebuild_by_gather(params, optimizers, N, src, kind, torch.arange(N, dtype=torch.int32, device=dev), kind_m)
+        lo, ls = torch.logit(new_o), torch.log(new_s)
+        o, sc = params["opacities"].data, params["scales"].data
+        o[sampled] = lo.reshape(o[sampled].shape)
+        o[dead] = lo.reshape(o[dead].shape)
+        sc[sampled] = ls
+        sc[dead] = ls
+        for k, v in state.items():
+            if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == N:
+                v[sampled] = 0
+        return
 
     def param_fn(name: str, p: Tensor) -> Tensor:
         p = p.detach().clone()
@@ -478,6 +570,25 @@ def sample_add(params, optimizers, state, n: int, binoms: Tensor, min_opacity: f
         opacities[sampled], torch.exp(params["scales"])[sampled],
         torch.bincount(sampled, minlength=len(opacities))[sampled] + 1, binoms)
     new_o = torch.clamp(new_o, max=1.0 - eps, min=min_opacity)
+    if _gather_ok(params):
+        # one gather per tensor group: rows [0, N) kept, rows [N, N + n) = the sampled rows (moments zero),
+        # then the new opacity / scale of the sampled rows and of their copies
+        N = len(opacities)
+        dev = opacities.device
+        src = torch.cat([torch.arange(N, dtype=torch.int32, device=dev), sampled.int()])
+        kind = torch.zeros(N + n, dtype=torch.uint8, device=dev)
+        kind[N:] = 1
+        _rebuild_by_gather(params, optimizers, N + n, src, kind)
+        lo, ls = torch.logit(new_o), torch.log(new_s)
+        o, sc = params["opacities"].data, params["scales"].data
+        o[sampled] = lo.reshape(o[sampled].shape)
+        o[N:] = lo.reshape(o[N:].shape)
+        sc[sampled] = ls
+        sc[N:] = ls
+        for k, v in state.items():
+            if isinstance(v, Tensor) and v.dim() > 0 and v.shape[0] == N:
+                state[k] = torch.cat([v, torch.zeros((n, *v.shape[1:]), device=v.device, dtype=v.dtype)])
+        return
 
     def param_fn(name: str, p: Tensor) -> Tensor:
         p = p.detach().clone()

@@ -394,6 +394,10 @@ int gsr_relocation(int n, const float *opacities, const float *scales, const int
                    void *stream);
 int gsr_inject_noise(int N, float *means, const float *quats, const float *log_scales,
                      const float *logit_opacities, const float *noise, float scaler, void *stream);
+/* gsplat.strategy.ops.reset_opa in place: logit_opacities[i] = min(logit_opacities[i], max_logit) and the
+ * opacity optimizer's moments (either may be NULL) cleared (DefaultStrategy.reset_every). */
+int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_avg, float *exp_avg_sq, float max_logit,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.

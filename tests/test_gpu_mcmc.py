@@ -94,3 +94,60 @@ def test_mcmc_training_relocates_dead_and_grows_to_cap():
     # nothing is left at the dead opacity: relocated onto alive Gaussians (>= min_opacity)
     assert float(torch.sigmoid(splats["opacities"].detach()).min()) >= strat.min_opacity * 0.5
     assert all(math.isfinite(x) for x in losses)
+
+
+def _mcmc_world(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"means": (n, 3), "quats": (n, 4), "scales": (n, 3), "opacities": (n,), "sh0": (n, 1, 3), "shN": (n, 15, 3)}
+    params = torch.nn.ParameterDict({k: torch.nn.Parameter((torch.randn(*s, generator=g) * 0.5).cuda()) for k, s in shapes.items()})
+    params["scales"].data.sub_(3.0)
+    opts = {k: torch.optim.Adam([params[k]], lr=1e-3) for k in shapes}
+    for k, o in opts.items():                                   # non-trivial moments
+        o.state[params[k]] = {"step": torch.tensor(7.0), "exp_avg": torch.randn(*shapes[k], generator=g).cuda(),
+                              "exp_avg_sq": torch.rand(*shapes[k], generator=g).cuda()}
+    return params, opts
+
+
+@pytest.mark.parametrize("op", ["relocate", "sample_add", "reset_opa"])
+def test_gather_launch_paths_equal_the_tensor_ops(op, monkeypatch):
+    """relocate / sample_add rebuilt by `gsr_refine_gather` and reset_opa by `gsr_reset_opacity` leave
+    exactly the parameters, Adam moments and strategy state of the tensor-op formulation they
+    replace (gsplat.strategy.ops relocate / sample_add / reset_opa), same multinomial draws."""
+    st_ = S()
+    n = 3000
+    outs = []
+    for use_kernels in (False, True):
+        params, opts = _mcmc_world(n, 5)
+        state = {"binoms": st_.MCMCStrategy().initialize_state()["binoms"], "stat": torch.arange(n, dtype=torch.float32).cuda()}
+        if not use_kernels:
+            monkeypatch.setattr(st_, "_gather_ok", lambda p: False)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        if op == "relocate":
+            dead = torch.zeros(n, dtype=torch.bool, device="cuda")
+            dead[::7] = True
+            st_.relocate(params, opts, state, dead, state["binoms"], generator=gen)
+        elif op == "sample_add":
+            st_.sample_add(params, opts, state, 450, state["binoms"], generator=gen)
+        else:
+            if not use_kernels:        # the tensor-op formulation, spelled out
+                mx = math.log(0.01 / 0.99)
+                st_._update_param_with_optimizer(lambda nm, p: torch.clamp(p, max=mx), lambda k, v: torch.zeros_like(v),
+                                                 params, opts, names=["opacities"])
+            else:
+                st_.reset_opa(params, opts, state, value=0.01)
+        monkeypatch.undo()
+        rec = {k: p.detach().clone() for k, p in params.items()}
+        for k, o in opts.items():
+            s = o.state[params[k]]
+            assert float(s["step"]) == 7.0
+            rec[k + ".m"], rec[k + ".v"] = s["exp_avg"].clone(), s["exp_avg_sq"].clone()
+        rec["stat"] = state["stat"].clone()
+        outs.append(rec)
+    a, b = outs
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    if op == "sample_add":
+        assert len(b["means"]) == n + 450 and float(b["means.m"][n:].abs().max()) == 0.0
+    if op == "reset_opa":
+        assert float(b["opacities"].max()) <= math.log(0.01 / 0.99) + 1e-6 and float(b["opacities.v"].abs().max()) == 0.0
