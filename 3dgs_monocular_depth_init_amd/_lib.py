@@ -57,6 +57,7 @@ SIGNATURES["gsr_strategy_accumulate"] = [_i, _i, _p, _i, _p, _f, _f, _p, _p, _p,
 SIGNATURES["gsr_relocation"] = [_i, _p, _p, _p, _p, _i, _p, _p, _p]
 SIGNATURES["gsr_inject_noise"] = [_i, _p, _p, _p, _p, _p, _f, _p]
 SIGNATURES["gsr_reset_opacity"] = [_i64, _p, _p, _p, _f, _p]
+SIGNATURES["gsr_sparse_adam_step"] = [_i, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES["gsr_refine_decide"] = [_i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _i, _p, _p]
 SIGNATURES["gsr_refine_plan"] = [_i, _p, _p, _i, _i, _i, _p, _p, _p]
 SIGNATURES["gsr_refine_gather"] = [_i, _i, _p, _p, _p, _p, _p, _p, _p]

@@ -444,6 +444,71 @@ extern "C" int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_a
   return GSR_OK;
 }
 
+namespace gsr {
+// torch.optim.SparseAdam (the reference's optimizer under cfg.sparse_grad, runner.py:130, 661-679) on the
+// rows a step actually rendered: row r of every tensor is updated iff visible[r] != 0, every other row --
+// parameter AND moments -- is left alone. Arithmetic as torch/optim/_functional.py sparse_adam:
+//   m += (g - m) (1 - b1);  v += (g^2 - v) (1 - b2);  p -= step_size * m / (sqrt(v) + eps),
+//   step_size = lr sqrt(1 - b2^t) / (1 - b1^t)  (eps is NOT divided by the bias correction, unlike Adam).
+constexpr int SPARSE_ADAM_MAX_TENSORS = 8;
+struct SparseAdamArgs {
+  float *p[SPARSE_ADAM_MAX_TENSORS];
+  const float *g[SPARSE_ADAM_MAX_TENSORS];
+  float *m[SPARSE_ADAM_MAX_TENSORS], *v[SPARSE_ADAM_MAX_TENSORS];
+  int row_len[SPARSE_ADAM_MAX_TENSORS];
+  float step_size[SPARSE_ADAM_MAX_TENSORS];
+  int64_t first[SPARSE_ADAM_MAX_TENSORS + 1];   // element ranges of the tensors in the flat index space
+  int n;
+  float omb1, omb2, eps;
+};
+__global__ void __launch_bounds__(256)
+sparse_adam_kernel(SparseAdamArgs a, const uint8_t *__restrict__ visible) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.first[a.n]) return;
+  int t = 0;
+  while (i >= a.first[t + 1]) ++t;
+  const int64_t e = i - a.first[t];
+  if (!visible[e / a.row_len[t]]) return;
+  const float g = a.g[t][e];
+  float m = a.m[t][e], v = a.v[t][e];
+  m = m + (g - m) * a.omb1;
+  v = v + (g * g - v) * a.omb2;
+  a.m[t][e] = m;
+  a.v[t][e] = v;
+  a.p[t][e] = a.p[t][e] + (-a.step_size[t]) * (m / (sqrtf(v) + a.eps));
+}
+}  // namespace gsr
+
+extern "C" int gsr_sparse_adam_step(int n, int64_t rows, const uint8_t *visible, void *const *params,
+                                    const void *const *grads, void *const *exp_avg, void *const *exp_avg_sq,
+                                    const int32_t *row_len, const float *step_size, double beta1, double beta2,
+                                    double eps, void *stream) {
+  GSR_REQUIRE(n >= 0 && n <= gsr::SPARSE_ADAM_MAX_TENSORS && rows >= 0, "sparse_adam_step: n=%d rows=%lld", n, (long long)rows);
+  if (n == 0 || rows == 0) return GSR_OK;
+  GSR_REQUIRE(visible && params && grads && exp_avg && exp_avg_sq && row_len && step_size, "sparse_adam_step: null array");
+  gsr::SparseAdamArgs a;
+  a.first[0] = 0;
+  for (int t = 0; t < n; ++t) {
+    GSR_REQUIRE(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t] && row_len[t] > 0, "sparse_adam_step: tensor %d", t);
+    a.p[t] = (float *)params[t];
+    a.g[t] = (const float *)grads[t];
+    a.m[t] = (float *)exp_avg[t];
+    a.v[t] = (float *)exp_avg_sq[t];
+    a.row_len[t] = row_len[t];
+    a.step_size[t] = step_size[t];
+    a.first[t + 1] = a.first[t] + rows * row_len[t];
+  }
+  a.n = n;
+  a.omb1 = (float)(1.0 - beta1);
+  a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps;
+  const int64_t blocks = gsr::ceil_div64(a.first[n], 256);
+  GSR_REQUIRE(blocks < 2147483647LL, "sparse_adam_step: too many elements");
+  hipLaunchKernelGGL(gsr::sparse_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, visible);
+  GSR_CHECK_LAUNCH("sparse_adam_step");
+  return GSR_OK;
+}
+
 extern "C" int gsr_inject_noise(int N, float *means, const float *quats, const float *log_scales,
                                 const float *logit_opacities, const float *noise, float scaler,
                                 void *stream) {

@@ -228,6 +228,86 @@ class FusedAdam:
         return [_Member(self, i) for i in range(len(self.optimizers))]
 
 
+class FusedSparseAdam:
+    """The reference's `sparse_grad` optimizers -- one torch.optim.SparseAdam per parameter tensor
+    (runner.py:130), stepped on sparse gradients over `info["gaussian_ids"]` (runner.py:661-679) -- behind
+    the same objects (param_groups for the schedulers, state[p]["step" / "exp_avg" / "exp_avg_sq"]), with
+    all six updates in ONE launch (`gsr_sparse_adam_step`): rows of Gaussians the step rendered get
+    SparseAdam's update, every other row keeps its parameter and its moments. `step(info)` takes the
+    rasterizer's `info` (its `radii` decide the rows)."""
+
+    def __init__(self, optimizers: Dict[str, torch.optim.Optimizer]):
+        for name, opt in optimizers.items():
+            if not isinstance(opt, torch.optim.SparseAdam):
+                raise TypeError(f"optimizer {name!r} is {type(opt).__name__}, expected torch.optim.SparseAdam")
+            if len(opt.param_groups) != 1 or len(opt.param_groups[0]["params"]) != 1:
+                raise ValueError("FusedSparseAdam expects one parameter per optimizer (runner.py:129-137)")
+            if opt.param_groups[0].get("maximize", False):
+                raise NotImplementedError("maximize is not built")
+        if len(optimizers) > 8:
+            raise ValueError("at most 8 tensors per fused launch")
+        self.optimizers = optimizers
+
+    def __getitem__(self, k):
+        return self.optimizers[k]
+
+    def __contains__(self, k):
+        return k in self.optimizers
+
+    def keys(self):
+        return self.optimizers.keys()
+
+    def items(self):
+        return self.optimizers.items()
+
+    def values(self):
+        return self.optimizers.values()
+
+    @torch.no_grad()
+    def step(self, info) -> None:
+        radii = info["radii"]
+        visible = (radii > 0).all(-1).any(0).to(torch.uint8).contiguous()       # [N]: rendered by some camera
+        rows = visible.numel()
+        P, G, M, V, L, S = [], [], [], [], [], []
+        beta1 = beta2 = eps = None
+        for name, opt in self.optimizers.items():
+            grp = opt.param_groups[0]
+            p = grp["params"][0]
+            if p.grad is None:
+                continue
+            if p.grad.is_sparse:
+                raise ValueError("FusedSparseAdam takes the dense gradients of the rasterizer (zero rows elsewhere)")
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] == rows):
+                raise ValueError("FusedSparseAdam: parameters must be contiguous fp32 ROCm tensors of N rows")
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            t = float(st["step"])
+            b1, b2 = grp["betas"]
+            if beta1 is None:
+                beta1, beta2, eps = float(b1), float(b2), float(grp["eps"])
+            elif (float(b1), float(b2), float(grp["eps"])) != (beta1, beta2, eps):
+                raise ValueError("FusedSparseAdam: all parameters must share betas and eps")
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            P.append(p.data_ptr()); G.append(g.data_ptr())
+            M.append(st["exp_avg"].data_ptr()); V.append(st["exp_avg_sq"].data_ptr())
+            L.append(p.numel() // max(rows, 1))
+            S.append(float(grp["lr"]) * (1.0 - beta2 ** t) ** 0.5 / (1.0 - beta1 ** t))
+        n = len(P)
+        if n == 0 or rows == 0:
+            return
+        PA = C.c_void_p * n
+        call("gsr_sparse_adam_step", n, rows, visible.data_ptr(), PA(*P), PA(*G), PA(*M), PA(*V),
+             (C.c_int32 * n)(*L), (C.c_float * n)(*S), beta1, beta2, eps, torch.cuda.current_stream().cuda_stream)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for opt in self.optimizers.values():
+            opt.zero_grad(set_to_none=set_to_none)
+
+
 class _Member:
     def __init__(self, parent: FusedAdam, index: int):
         self.parent, self.index = parent, index

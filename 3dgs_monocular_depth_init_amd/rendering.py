@@ -637,8 +637,9 @@ def rasterization(
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
     memory layout, never the rendered result: both values run the same dense
-    [C,N] kernels here (and `meta` keeps the dense layout), `sparse_grad`
-    (needs packed indices) is rejected.
+    [C,N] kernels here (and `meta` keeps the dense layout); `sparse_grad=True` (with
+    packed=True) adds `meta["camera_ids"]` / `meta["gaussian_ids"]` of the rendered pairs and leaves
+    the gradients dense (zero rows elsewhere) for `optim.FusedSparseAdam`.
 
     Private extensions used by `runner.rasterize_splats` (not part of gsplat's
     signature): `_raw_activations=True` means `scales` are log-scales and
@@ -661,8 +662,8 @@ def rasterization(
             "view-parallel replicas (`distributed.GradSync` / `distributed.GatherRowsSync`) and "
             "call with distributed=False"
         )
-    if sparse_grad:
-        raise NotImplementedError("sparse_grad=True needs packed indices; not built")
+    if sparse_grad and not packed:
+        raise ValueError("sparse_grad=True only works with packed=True (as in gsplat)")
     if tile_size != TILE:
         raise NotImplementedError(f"tile_size={tile_size}: kernels are built for {TILE}")
     if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
@@ -779,8 +780,15 @@ def rasterization(
             [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)],
             dim=-1)
 
+    camera_ids = gaussian_ids = None
+    if sparse_grad:
+        # what gsplat's packed mode reports and runner.py:661-672 builds its sparse gradients over: the
+        # (camera, Gaussian) pairs that are rendered. (The gradients themselves stay dense here, exact
+        # zeros on the other rows: `optim.FusedSparseAdam` / torch.sparse_coo_tensor select the rows.)
+        vis = (radii > 0).all(-1).flatten().nonzero(as_tuple=True)[0]
+        camera_ids, gaussian_ids = vis // N, vis % N
     meta = {
-        "camera_ids": None, "gaussian_ids": None,
+        "camera_ids": camera_ids, "gaussian_ids": gaussian_ids,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
         "opacities": opac, "tile_width": tile_w, "tile_height": tile_h,
         "tiles_per_gauss": tpg, "isect_ids": isect_keys, "flatten_ids": flatten_ids,

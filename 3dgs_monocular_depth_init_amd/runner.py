@@ -51,6 +51,7 @@ def create_splats_with_optimizers(
     quats: Optional[Tensor] = None,
     opacities_logit: Optional[Tensor] = None,
     shN: Optional[Tensor] = None,
+    sparse_grad: bool = False,          # runner.py:63, 130: torch.optim.SparseAdam instead of Adam
 ) -> Tuple[torch.nn.ParameterDict, Dict[str, torch.optim.Optimizer]]:
     """runner.py:53-138 without the dataset parser: the caller supplies the
     point cloud. Unlike the reference (which shards Gaussians over ranks,
@@ -78,7 +79,7 @@ def create_splats_with_optimizers(
     ).to(device)
     BS = batch_size * world_size                                         # runner.py:128-137
     optimizers = {
-        name: torch.optim.Adam(
+        name: (torch.optim.SparseAdam if sparse_grad else torch.optim.Adam)(
             [{"params": splats[name], "lr": lr * math.sqrt(BS), "name": name}],
             eps=1e-15 / math.sqrt(BS),
             betas=(1 - BS * (1 - 0.9), 1 - BS * (1 - 0.999)),
@@ -95,6 +96,7 @@ class RasterConfig:
     near_plane: float = 0.01
     far_plane: float = 1e10
     packed: bool = False
+    sparse_grad: bool = False           # config.py:147 (needs packed; SparseAdam on the rendered rows)
     antialiased: bool = False
     absgrad: bool = False
     camera_model: str = "pinhole"
@@ -128,7 +130,7 @@ def rasterize_splats(
     render_colors, render_alphas, info = rasterization(
         means=means, quats=quats, scales=splats["scales"], opacities=splats["opacities"],
         colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
-        packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=False,
+        packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=cfg.sparse_grad,
         rasterize_mode=rasterize_mode, distributed=False, camera_model=cfg.camera_model,
         _raw_activations=True, _campos=campos, _tight_tiles=cfg.tight_tiles, **kwargs,
     )
@@ -207,10 +209,24 @@ def train_step(
         else:
             strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
     if optimizers is not None:
-        if hasattr(optimizers, "step"):                                  # FusedAdam: one launch
+        from .optim import FusedSparseAdam
+        if isinstance(optimizers, FusedSparseAdam):                      # cfg.sparse_grad, one launch
+            optimizers.step(info)
+            optimizers.zero_grad(set_to_none=True)
+        elif hasattr(optimizers, "step"):                                # FusedAdam: one launch
             optimizers.step()
             optimizers.zero_grad(set_to_none=True)
         else:
+            if cfg.sparse_grad:                                          # runner.py:661-672, literally
+                assert cfg.packed, "Sparse gradients only work with packed mode."
+                gaussian_ids = info["gaussian_ids"]
+                for k in splats.keys():
+                    grad = splats[k].grad
+                    if grad is None or grad.is_sparse:
+                        continue
+                    splats[k].grad = torch.sparse_coo_tensor(
+                        indices=gaussian_ids[None], values=grad[gaussian_ids], size=splats[k].size(),
+                        is_coalesced=len(Ks) == 1)
             for opt in optimizers.values():                              # runner.py:676-679
                 opt.step()
                 opt.zero_grad(set_to_none=True)

@@ -398,6 +398,15 @@ int gsr_inject_noise(int N, float *means, const float *quats, const float *log_s
  * opacity optimizer's moments (either may be NULL) cleared (DefaultStrategy.reset_every). */
 int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_avg, float *exp_avg_sq, float max_logit,
                       void *stream);
+/* torch.optim.SparseAdam over the rows a step rendered (cfg.sparse_grad: runner.py:130 builds SparseAdam,
+ * runner.py:661-672 turns every gradient into a sparse tensor over info["gaussian_ids"]): for each of the n
+ * tensors [rows, row_len[t]], row r is updated iff visible[r] != 0 -- parameter and both moments; all other
+ * rows are untouched. step_size[t] = lr sqrt(1 - beta2^t) / (1 - beta1^t); the arithmetic order is
+ * torch/optim/_functional.py sparse_adam's. HOST pointer arrays, n <= 8. */
+int gsr_sparse_adam_step(int n, int64_t rows, const uint8_t *visible, void *const *params,
+                         const void *const *grads, void *const *exp_avg, void *const *exp_avg_sq,
+                         const int32_t *row_len, const float *step_size, double beta1, double beta2,
+                         double eps, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Init path (monocular depth -> seed point cloud), SURVEY.md rows B1-B9.

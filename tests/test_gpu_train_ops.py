@@ -593,3 +593,53 @@ def test_half_packed_rows_on_real_gradient_rows(monkeypatch):
         parity_log.record("fp16_rows", tensor=n_, l2_rel=l2, max_rel=mx, rows_visible=int(vis.sum()),
                           median_pos_to_row_max=float(ratio.median()), q10_pos_to_row_max=q10)
         assert l2 <= 2e-3, (n_, l2)
+
+
+def test_sparse_grad_one_launch_equals_reference_sparse_adam():
+    """cfg.sparse_grad (runner.py:130, 661-679): torch.optim.SparseAdam on sparse gradients over
+    info["gaussian_ids"]. `optim.FusedSparseAdam` (gsr_sparse_adam_step, one launch over the rendered
+    rows) must leave the parameters and moments of the literal path -- sparse_coo_tensor + six
+    SparseAdam.step() -- including the rows that are never rendered (a third of the scene is far
+    outside every frustum: untouched parameter, zero moments)."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
+    N = 3000
+    sc = scenes.make_scene(N, 2, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    means = sc["means"].clone()
+    means[::3] += torch.tensor([0.0, 500.0, 0.0])         # far outside every frustum
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 30, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    cfg = runner.RasterConfig(packed=True, sparse_grad=True)
+
+    def run(fused):
+        splats, opts = runner.create_splats_with_optimizers(
+            means, torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"], sparse_grad=True)
+        assert all(isinstance(o, torch.optim.SparseAdam) for o in opts.values())
+        start = {n: p.detach().clone() for n, p in splats.items()}
+        o = optim.FusedSparseAdam(opts) if fused else opts
+        seen = torch.zeros(N, dtype=torch.bool, device="cuda")
+        for k, step in enumerate((5000, 5001, 5002)):
+            _, info = runner.train_step(splats, o, c2w[k:k + 1], K[k:k + 1], target, cfg=cfg, step=step)
+            assert info["gaussian_ids"].dtype == torch.int64 and (info["camera_ids"] == 0).all()
+            seen[info["gaussian_ids"]] = True
+            assert all(p.grad is None for p in splats.values())
+        torch.cuda.synchronize()
+        state = {n: {a: (b.clone() if torch.is_tensor(b) else b) for a, b in opts[n].state[splats[n]].items()} for n in splats}
+        return start, {n: p.detach().clone() for n, p in splats.items()}, state, seen
+
+    s0, p_ref, st_ref, seen = run(False)
+    _, p_fus, st_fus, seen2 = run(True)
+    assert torch.equal(seen, seen2) and 0.3 < float(seen.float().mean()) < 0.7
+    for n in p_ref:
+        assert int(st_fus[n]["step"]) == 3 == int(st_ref[n]["step"]), n
+        assert torch.allclose(p_ref[n], p_fus[n], rtol=1e-6, atol=1e-7), n
+        for a in ("exp_avg", "exp_avg_sq"):
+            x, y = st_ref[n][a], st_fus[n][a]
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-7 * float(x.abs().max()) + 1e-30), (n, a)
+            assert float(y[~seen].abs().max()) == 0.0, (n, a)              # never rendered: moments stay zero
+        assert torch.equal(p_fus[n][~seen], s0[n][~seen]), n                # ... and the parameter untouched
+    assert float((p_fus["means"][seen] - s0["means"][seen]).abs().max()) > 0.0
