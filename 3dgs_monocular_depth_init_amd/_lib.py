@@ -56,6 +56,10 @@ SIGNATURES["gsr_project_bwd_rows"] = [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f
 SIGNATURES["gsr_strategy_accumulate"] = [_i, _i, _p, _i, _p, _f, _f, _p, _p, _p, _f, _p]
 SIGNATURES["gsr_relocation"] = [_i, _p, _p, _p, _p, _i, _p, _p, _p]
 SIGNATURES["gsr_inject_noise"] = [_i, _p, _p, _p, _p, _p, _f, _p]
+SIGNATURES["gsr_rbf_workspace_bytes"] = [_i]          # returns int64 bytes (restype set in load())
+SIGNATURES["gsr_rbf_fit"] = [_i, _p, _p, C.c_double, _i, _p, _i64, _p, _p, _p]
+SIGNATURES["gsr_rbf_eval_grid"] = [_i, _p, _p, _p, _i, _i, _i, _p, _p]
+SIGNATURES["gsr_bilinear_ac_t"] = [_i, _i, _p, _i, _i, _p, _p]
 SIGNATURES["gsr_reset_opacity"] = [_i64, _p, _p, _p, _f, _p]
 SIGNATURES["gsr_sparse_adam_step"] = [_i, _i64, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES["gsr_refine_decide"] = [_i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _f, _f, _i, _p, _p]
@@ -141,6 +145,7 @@ def load():
             fn.argtypes = args
             fn.restype = C.c_int
         lib.gsr_pc_subsample_workspace_bytes.restype = C.c_int64
+        lib.gsr_rbf_workspace_bytes.restype = C.c_int64
         _lib = lib
         return lib
 

@@ -20,7 +20,7 @@ LIB_PATH = LIB_DIR / "libgsrast.so"
 STAMP = LIB_DIR / "libgsrast.stamp"
 ARCH = "gfx950"
 SOURCES = ["api.hip", "project.hip", "isect.hip", "isect_bucket.hip", "raster_fwd.hip", "raster_bwd.hip",
-           "init_depth.hip", "train_ops.hip", "ssim.hip", "knn.hip", "depthnet.hip", "pointcloud.hip"]
+           "init_depth.hip", "train_ops.hip", "ssim.hip", "knn.hip", "depthnet.hip", "pointcloud.hip", "rbf.hip"]
 FLAGS = ["-O3", "-std=c++17", "-shared", "-fPIC", f"--offload-arch={ARCH}",
          "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 

@@ -17,7 +17,11 @@ Neighbour ties: SfM pixels are integers, so several points can sit at exactly th
 K-th neighbour; which of them scikit-learn's KD-tree reports is an accident of its traversal. The
 kernels here break ties by point index. A classification can differ from the reference's only for
 a point with such a tie (tests/test_interp_golden.py checks exactly that).
-method="rbf" needs torchrbf (absent) and is not built.
+method="rbf" (interp.py:30-72): the reference fits a torchrbf.RBFInterpolator -- a port of
+scipy.interpolate.RBFInterpolator; neither is used here -- and this file runs the same published algorithm on
+the device in float64 (csrc/rbf.hip: dense LU of the (P + 3)-square system, grid evaluation, bilinear
+upsampling), restated and pinned against scipy in oracle/rbf_oracle.py / tests/test_rbf.py; parity against
+torchrbf itself is unpinned (the package is absent; it runs in float32).
 """
 from __future__ import annotations
 
@@ -112,11 +116,43 @@ def linear_interpolation(coords: torch.Tensor, values: torch.Tensor, config, dev
     return out.to(values.dtype)
 
 
+RBF_KERNELS = {"linear": 0, "thin_plate_spline": 1, "cubic": 2}
+
+
+def rbf_interpolation(coords: torch.Tensor, values: torch.Tensor, config, device, W: int, H: int) -> torch.Tensor:
+    """interp.py:30-72: RBF interpolant (kernel / smoothing of the config, polynomial of the kernel's minimum
+    degree) over the pixels normalised by (W - 1, H - 1), evaluated on a grid 256 pixels wide, upsampled
+    bilinearly (align_corners) to [H, W]. `gsr_rbf_fit` + `gsr_rbf_eval_grid` + `gsr_bilinear_ac_t`."""
+    if config.kernel not in RBF_KERNELS:
+        raise NotImplementedError(f"rbf kernel {config.kernel!r}: built are {sorted(RBF_KERNELS)}")
+    from ..._lib import load
+    lib = load()
+    dev = values.device if values.is_cuda else torch.device(device)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    P = coords.shape[1]
+    c = coords.to(dev).float()
+    sites = torch.stack([c[0] / (W - 1.0), c[1] / (H - 1.0)], dim=1).contiguous()            # coords_norm
+    vals = values.to(dev).float().contiguous()
+    nbytes = int(lib.gsr_rbf_workspace_bytes(P))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    coeffs = torch.empty(P + 3, dtype=torch.float64, device=dev)
+    ss = torch.empty(4, dtype=torch.float64, device=dev)
+    k = RBF_KERNELS[config.kernel]
+    call("gsr_rbf_fit", P, ptr(sites), ptr(vals), float(config.smoothing), k, ptr(ws), nbytes, ptr(coeffs), ptr(ss), st)
+    factor = max(W / 256, 1)
+    qw, qh = int(W / factor), int(H / factor)
+    grid = torch.empty(qw, qh, dtype=torch.float32, device=dev)
+    call("gsr_rbf_eval_grid", P, ptr(sites), ptr(coeffs), ptr(ss), k, qw, qh, ptr(grid), st)
+    out = torch.empty(H, W, dtype=torch.float32, device=dev)
+    call("gsr_bilinear_ac_t", qw, qh, ptr(grid), W, H, ptr(out), st)
+    return out.to(values.dtype)
+
+
 def interpolate_scale(coords, values, config, device, W, H):
     if config.method == "linear":
         return linear_interpolation(coords, values, config, device, W, H)
     if config.method == "rbf":
-        raise NotImplementedError("interp.method='rbf' needs torchrbf, which is not available; use 'linear'")
+        return rbf_interpolation(coords, values, config, device, W, H)
     raise ValueError(f"Unknown interpolation method: {config.method}")
 
 
@@ -140,6 +176,10 @@ def align_depth_interpolate(predicted_depth, sfm_points_camera_coords, gt_depth,
     device = predicted_depth.depth.device
     interp_config = config.mdi.alignment.interp
     prealigned = initial_alignment(predicted_depth, sfm_points_camera_coords, gt_depth, config, debug_export_dir)
+    # limit the number of points of the dense RBF system (interp.py:308-324, pick_rbf_point_subset :129-143)
+    if interp_config.method == "rbf" and interp_config.max_rbf_points != -1 and num_sfm_pts > interp_config.max_rbf_points:
+        indices = torch.randperm(num_sfm_pts, device=device)[:interp_config.max_rbf_points]
+        sfm_points_camera_coords, gt_depth = sfm_points_camera_coords[:, indices], gt_depth[indices]
     scale_factors = gt_depth / prealigned.aligned_depth[sfm_points_camera_coords[1], sfm_points_camera_coords[0]]
     outlier_mask = None
     if interp_config.scale_outlier_removal:

@@ -458,6 +458,26 @@ int gsr_sfm_patch_mask(int H, int W, int M, const int64_t *coords, int ph, int p
  * (`out` should be pre-filled with the fill value). */
 int gsr_tri_interp(int H, int W, int n_tri, const double *xy, const int32_t *tris, const double *values,
                    float *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * F4: interp.method = "rbf" (gs_init_compare/depth_alignment/alignment/interp.py:30-72): the reference fits a
+ * torchrbf.RBFInterpolator (= scipy.interpolate.RBFInterpolator's algorithm, no neighbours) to the scale
+ * factors at the SfM pixels normalised to [0,1]^2, evaluates it on a grid 256 pixels wide (x-major) and
+ * upsamples bilinearly with align_corners. kernel: 0 linear, 1 thin_plate_spline (the config's default),
+ * 2 cubic; polynomial degree = the kernel's minimum (0 / 1 / 1); epsilon = 1. All float64.
+ * gsr_rbf_fit: sites_xy [P,2] / values [P] fp32 -> coeffs [P+3] (P + 1 used by the linear kernel) and
+ *   shift_scale [4] = {shift_x, shift_y, scale_x, scale_y}; workspace of gsr_rbf_workspace_bytes(P).
+ *   Dense LU with partial pivoting; synchronises the stream once (singular-system report).
+ * gsr_rbf_eval_grid: out [qw, qh] fp32 = the interpolant at (a / (qw-1), b / (qh-1)).
+ * gsr_bilinear_ac_t: out [H, W] = F.interpolate(src[None, None] as [qw, qh], (W, H), "bilinear",
+ *   align_corners=True)[0, 0].T
+ * --------------------------------------------------------------------------*/
+int64_t gsr_rbf_workspace_bytes(int P);
+int gsr_rbf_fit(int P, const float *sites_xy, const float *values, double smoothing, int kernel, void *workspace,
+                int64_t workspace_bytes, double *coeffs, double *shift_scale, void *stream);
+int gsr_rbf_eval_grid(int P, const float *sites_xy, const double *coeffs, const double *shift_scale, int kernel,
+                      int qw, int qh, float *out, void *stream);
+int gsr_bilinear_ac_t(int qw, int qh, const float *src, int W, int H, float *out, void *stream);
 /* F4 tail (depth_alignment/segmentation/region_margin.py:21-35, `calculate_region_margin_mask`):
  * mask[i] = 1 where the (2*half_width+1)^2 box mean of the int32 label map (replicate padding),
  * snapped to the nearest integer when torch.isclose to it, equals the pixel's own label -- the
