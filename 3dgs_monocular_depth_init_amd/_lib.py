@@ -56,6 +56,7 @@ SIGNATURES["gsr_project_bwd_rows"] = [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f
 SIGNATURES["gsr_strategy_accumulate"] = [_i, _i, _p, _i, _p, _f, _f, _p, _p, _p, _f, _p]
 SIGNATURES["gsr_relocation"] = [_i, _p, _p, _p, _p, _i, _p, _p, _p]
 SIGNATURES["gsr_inject_noise"] = [_i, _p, _p, _p, _p, _p, _f, _p]
+SIGNATURES["gsr_sort_pairs_u64"] = [_i64, _p, _p, _p, _p, _p, _i64, _p]
 SIGNATURES["gsr_rbf_workspace_bytes"] = [_i]          # returns int64 bytes (restype set in load())
 SIGNATURES["gsr_rbf_fit"] = [_i, _p, _p, C.c_double, _i, _p, _i64, _p, _p, _p]
 SIGNATURES["gsr_rbf_eval_grid"] = [_i, _p, _p, _p, _i, _i, _i, _p, _p]

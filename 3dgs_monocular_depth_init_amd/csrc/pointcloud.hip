@@ -11,7 +11,7 @@
 // Not a translation of that stack machine: the splits are midpoints of a cube, so the whole tree is
 // fixed by each point's bit path (bit l = which half at level l). The path is computed per point
 // with the reference's own float arithmetic (split = (min + max) / 2, repeated), the points are
-// radix-sorted by path (rocPRIM), every node is then a contiguous range, and the tree is walked
+// radix-sorted by path (sort_pairs_u64 below), every node is then a contiguous range, and the tree is walked
 // LEVEL-SYNCHRONOUSLY: per level one statistics launch (count, sum of extents / positions / colours
 // in fp64, tight box by ordered-integer atomic min/max -- all order-independent) and one decision
 // launch over the points that are still unresolved. 63 levels at most; no recursion, no host sync.
@@ -19,8 +19,6 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 
@@ -318,14 +316,143 @@ struct Carver {     // bump allocator over the caller's workspace
   }
 };
 
+// ---- key sort and prefix sum (hand-written; rocPRIM served here until round 3) ----------------------
+// Stable LSD radix sort of (uint64 key, uint32 value) pairs, 8 bits per pass, eight passes over the 64 key
+// bits, ping-pong between the caller's two buffer pairs (an even number of passes: the result ends in the
+// buffers it started in). Per pass:
+//   rs_hist     tile of 2048 keys per workgroup -> 256 digit counts (LDS atomics) -> hist[digit][tile]
+//   scan_i32    exclusive prefix sum of hist, read digit-major: the global offset of (digit, tile)
+//   rs_scatter  the tile again in eight rounds of 256 keys in index order; a key's position is
+//               offset[digit][tile] + keys of that digit in earlier rounds (LDS counters)
+//               + keys of that digit in earlier waves of the round + its rank in the wave (match-any
+//               by eight ballots) -- every term counts keys that precede it in the input: stable.
+constexpr int RS_THREADS = 256, RS_ROUNDS = 8, RS_TILE = RS_THREADS * RS_ROUNDS, RS_DIGITS = 256;
+
+__global__ void __launch_bounds__(RS_THREADS)
+rs_hist_kernel(int64_t n, const uint64_t *__restrict__ keys, int shift, int n_tiles, int *__restrict__ hist) {
+  __shared__ int h[RS_DIGITS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+    const int64_t i = base + r * RS_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255)], 1);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive prefix sum of a[0..n) in place, one workgroup walking the array in chunks of 4096
+__global__ void __launch_bounds__(1024)
+scan_i32_kernel(int64_t n, const int *in, int *out) {   // (in == out allowed: a chunk is read before it is written)
+  __shared__ int wsum[16], carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 4096) {
+    const int64_t i0 = base + (int64_t)tid * 4;
+    int v[4], local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = i0 + k < n ? in[i0 + k] : 0;
+      local += v[k];
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int prefix = carry_s, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) prefix += wsum[w];
+      total += wsum[w];
+    }
+    int run = prefix + incl - local;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 0) carry_s += total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+rs_scatter_kernel(int64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                  uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int shift, int n_tiles,
+                  const int *__restrict__ offsets) {
+  __shared__ int run[RS_DIGITS], wcount[RS_THREADS / 64][RS_DIGITS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  run[tid] = offsets[(int64_t)tid * n_tiles + blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  for (int r = 0; r < RS_ROUNDS; ++r) {
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / 64; ++w) wcount[w][tid] = 0;
+    __syncthreads();
+    const int64_t i = base + r * RS_THREADS + tid;
+    const bool live = i < n;
+    const uint64_t key = live ? keys[i] : ~0ull;
+    const int d = (int)((key >> shift) & 255);
+    // lanes of this wave with the same digit (dead lanes, at the very end of the input, match only each other)
+    uint64_t same = __ballot(live);
+    same = live ? same : ~same;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bal = __ballot((d >> b) & 1);
+      same &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    const int rank = __popcll(same & ((1ull << lane) - 1));
+    if (live && rank == 0) wcount[wave][d] = __popcll(same);
+    __syncthreads();
+    if (live) {
+      int pos = run[d] + rank;
+      for (int w = 0; w < wave; ++w) pos += wcount[w][d];
+      keys_out[pos] = key;
+      vals_out[pos] = vals[i];
+    }
+    __syncthreads();
+    int add = 0;
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / 64; ++w) add += wcount[w][tid];
+    run[tid] += add;
+    __syncthreads();
+  }
+}
+
+static inline int rs_tiles(int64_t n) { return (int)ceil_div64(n > 0 ? n : 1, RS_TILE); }
+static inline int64_t rs_hist_ints(int64_t n) { return (int64_t)RS_DIGITS * rs_tiles(n); }
+
+// sorts (keys, vals) by key, ascending and stable; keys_alt / vals_alt / hist are scratch
+static int sort_pairs_u64(int64_t n, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                          int *hist, hipStream_t st) {
+  if (n <= 0) return GSR_OK;
+  const int tiles = rs_tiles(n);
+  uint64_t *ka = keys, *kb = keys_alt;
+  uint32_t *va = vals, *vb = vals_alt;
+  for (int pass = 0; pass < 8; ++pass) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(tiles), dim3(RS_THREADS), 0, st, n, ka, pass * 8, tiles, hist);
+    hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, rs_hist_ints(n), hist, hist);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(tiles), dim3(RS_THREADS), 0, st, n, ka, va, kb, vb, pass * 8, tiles, hist);
+    uint64_t *tk = ka; ka = kb; kb = tk;
+    uint32_t *tv = va; va = vb; vb = tv;
+  }
+  return GSR_OK;
+}
+
 struct Layout {
   uint64_t *codes_in, *codes_out;
   uint32_t *idx_in, *idx_out;
   int *mm;
   float *cube;
   Work w;
-  void *sort_tmp, *scan_tmp;
-  size_t sort_bytes, scan_bytes, total;
+  int *sort_hist;
+  size_t total;
 };
 
 static Layout carve(void *ws, int N) {
@@ -340,8 +467,8 @@ static Layout carve(void *ws, int N) {
   L.cube = c.take<float>(8);
   Work &w = L.w;
   w.N = N;
-  w.code = L.codes_out;
-  w.idx = L.idx_out;
+  w.code = L.codes_in;     // the eight-pass sort ends in the buffers it started in
+  w.idx = L.idx_in;
   w.pos = c.take<float>(3 * n);
   w.rgb = c.take<float>(3 * n);
   w.ext = c.take<float>(n);
@@ -360,14 +487,7 @@ static Layout carve(void *ws, int N) {
   w.m_rgb = c.take<float>(3 * n);
   w.emit = c.take<int>(n);
   w.offs = c.take<int>(n);
-  L.sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, L.sort_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                  (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64, (hipStream_t)0);
-  L.scan_bytes = 0;
-  (void)rocprim::exclusive_scan(nullptr, L.scan_bytes, (int *)nullptr, (int *)nullptr, 0, n,
-                                rocprim::plus<int>(), (hipStream_t)0);
-  L.sort_tmp = c.take<char>(L.sort_bytes);
-  L.scan_tmp = c.take<char>(L.scan_bytes);
+  L.sort_hist = c.take<int>((size_t)rs_hist_ints((int64_t)n));
   L.total = c.off + 256;
   return L;
 }
@@ -385,6 +505,19 @@ extern "C" int gsr_pc_min_extents(int N, int C, const float *points, const float
   hipLaunchKernelGGL(min_extents_kernel, dim3((unsigned)gsr::ceil_div(N, 256)), dim3(256), 0,
                      (hipStream_t)stream, N, C, points, Ks, Ps, image_sizes, extents);
   GSR_CHECK_LAUNCH("pc_min_extents");
+  return GSR_OK;
+}
+
+// The sort by itself (tests; the subsampler calls it on its Morton codes). keys / vals are sorted in place,
+// keys_alt / vals_alt [n] and hist [256 * ceil(n / 2048)] int32 are scratch.
+extern "C" int gsr_sort_pairs_u64(int64_t n, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                                  int32_t *hist, int64_t hist_ints, void *stream) {
+  GSR_REQUIRE(n >= 0, "sort_pairs_u64: bad n");
+  if (n == 0) return GSR_OK;
+  GSR_REQUIRE(keys && keys_alt && vals && vals_alt && hist && hist_ints >= rs_hist_ints(n),
+              "sort_pairs_u64: null pointer or %lld < %lld histogram words", (long long)hist_ints, (long long)rs_hist_ints(n));
+  sort_pairs_u64(n, keys, keys_alt, vals, vals_alt, hist, (hipStream_t)stream);
+  GSR_CHECK_LAUNCH("sort_pairs_u64");
   return GSR_OK;
 }
 
@@ -414,8 +547,7 @@ extern "C" int gsr_pc_subsample(int N, const float *points, const float *rgbs, c
   hipLaunchKernelGGL(bbox_kernel, grid, block, 0, st, N, points, L.mm);
   hipLaunchKernelGGL(cube_kernel, dim3(1), dim3(64), 0, st, L.mm, L.cube);
   hipLaunchKernelGGL(codes_kernel, grid, block, 0, st, N, points, L.cube, L.codes_in, L.idx_in);
-  GSR_CHECK_HIP(rocprim::radix_sort_pairs(L.sort_tmp, L.sort_bytes, L.codes_in, L.codes_out, L.idx_in,
-                                          L.idx_out, (size_t)N, 0, 64, st));
+  sort_pairs_u64(N, L.codes_in, L.codes_out, L.idx_in, L.idx_out, L.sort_hist, st);
   hipLaunchKernelGGL(gather_kernel, grid, block, 0, st, L.w, points, rgbs, extents, L.cube);
   for (int level = 0; level <= MAX_LEVELS; ++level) {
     hipLaunchKernelGGL(clear_stats_kernel, grid, block, 0, st, L.w);
@@ -424,8 +556,7 @@ extern "C" int gsr_pc_subsample(int N, const float *points, const float *rgbs, c
                        min_extent_multiplier);
   }
   hipLaunchKernelGGL(emit_flags_kernel, grid, block, 0, st, L.w);
-  GSR_CHECK_HIP(rocprim::exclusive_scan(L.scan_tmp, L.scan_bytes, L.w.emit, L.w.offs, 0, (size_t)N,
-                                        rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, (int64_t)N, L.w.emit, L.w.offs);
   hipLaunchKernelGGL(emit_kernel, grid, block, 0, st, L.w, out_points, out_rgbs, out_count);
   GSR_CHECK_LAUNCH("pc_subsample");
   return GSR_OK;

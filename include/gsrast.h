@@ -638,6 +638,11 @@ int gsr_pc_min_extents(int N, int C, const float *points, const float *Ks, const
  * nodes merged into their mean when compact enough. Outputs are written in tree (bit-path) order:
  * out_points / out_rgbs [<= N,3], *out_count on the device. workspace: device scratch of at least
  * gsr_pc_subsample_workspace_bytes(N) bytes (returns -1 for N < 0). */
+/* The subsampler's key sort by itself: (uint64 key, uint32 value) pairs sorted in place by key, ascending,
+ * stable (hand-written LSD radix sort, eight 8-bit passes). keys_alt / vals_alt [n] and
+ * hist [256 * ceil(n / 2048)] int32 are scratch. */
+int gsr_sort_pairs_u64(int64_t n, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                       int32_t *hist, int64_t hist_ints, void *stream);
 int64_t gsr_pc_subsample_workspace_bytes(int N);
 int gsr_pc_subsample(int N, const float *points, const float *rgbs, const float *extents,
                      float max_bbox_aspect_ratio, float min_extent_multiplier, void *workspace,

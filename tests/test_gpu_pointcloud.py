@@ -76,3 +76,28 @@ def test_c3_sized_cloud_and_pipeline_hook():
     cfg.mdi.postprocess.subsample_params = params
     q, qc, _ = mdi._finish(cfg, [pts], [rgb], "cuda", ([k.numpy() for k in Ks], [m.numpy() for m in Ps], sizes.numpy()))
     assert q.shape[0] == p.shape[0]
+
+
+@pytest.mark.parametrize("n", [1, 255, 2047, 2048, 2049, 300_001, 2_500_000])
+def test_hand_written_key_sort_is_the_stable_sort(n):
+    """gsr_sort_pairs_u64 (csrc/pointcloud.hip: eight-pass LSD radix sort, the subsampler's Morton-code
+    sort) against numpy's stable argsort: full 64-bit keys, heavy duplication (stability shows in the
+    values), tile and round boundaries (2048 keys per workgroup, 256 per round)."""
+    import numpy as np
+    lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+    keys[rng.random(n) < 0.5] &= np.uint64(0xFF0000FF000000FF)            # many equal keys, all bytes exercised
+    if n > 10:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]                       # exact duplicates far apart
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    k = torch.from_numpy(keys.view(np.int64)).cuda()
+    v = torch.from_numpy(vals.view(np.int32)).cuda()
+    k2, v2 = torch.empty_like(k), torch.empty_like(v)
+    tiles = (n + 2047) // 2048
+    hist = torch.empty(256 * tiles, dtype=torch.int32, device="cuda")
+    lib.call("gsr_sort_pairs_u64", n, k.data_ptr(), k2.data_ptr(), v.data_ptr(), v2.data_ptr(), hist.data_ptr(),
+             hist.numel(), torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(k.cpu().numpy().view(np.uint64), keys[order])
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order])
