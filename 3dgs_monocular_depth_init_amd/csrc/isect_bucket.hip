@@ -522,6 +522,20 @@ tile_order_kernel(int n, const int32_t *__restrict__ tile_offsets, int32_t *__re
   tile_order_body(n, tile_offsets, tile_order, threadIdx.x, 1024);
 }
 
+#ifdef GSR_SORT_TIMELINE
+__device__ unsigned long long *g_sort_timeline = nullptr;
+#define SORT_STAMP(k)                                                                     \
+  do {                                                                                    \
+    __syncthreads();                                                                      \
+    if (threadIdx.x == 0 && g_sort_timeline) {                                            \
+      unsigned long long t_;                                                              \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+      g_sort_timeline[8 * blockIdx.x + (k)] = t_;                                         \
+    }                                                                                     \
+  } while (0)
+#else
+#define SORT_STAMP(k)
+#endif
 // Pass 3: one workgroup per bucket. The bucket's region holds its listed pairs (and, for tight
 // lists, sentinels in the slots the rectangle rule reserved for dropped pairs). The real keys are
 // split by tile-in-bucket while they are loaded into LDS (8-bin counting sort), then the 8 tile
@@ -538,6 +552,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], seg_cur[BK_TILES], npad_max_s;
   __shared__ int32_t red[BK_THREADS / 64], out_base_s;
   const int tid = threadIdx.x;
+  SORT_STAMP(0);
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
   // `capacity` = entries the key / id buffers hold. The caller may size them from the
   // previous frame without waiting for this frame's total: everything is clamped so an
@@ -559,11 +574,13 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       out_base_s = t;
     }
   }
+  SORT_STAMP(1);
   for (int t = tid; t < LA; t += BK_THREADS) {
     const uint64_t k = keys[s + t];
     if (k != BK_SENTINEL) atomicAdd(&seg_cnt[(int)(k >> 61)], 1);
   }
   __syncthreads();
+  SORT_STAMP(2);
   const int out_base = out_base_s;
   if (tid == 0) {
     int run = 0, mx = 0;
@@ -594,9 +611,12 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       if (k != BK_SENTINEL) sk[atomicAdd(&seg_cur[(int)(k >> 61)], 1)] = k;
     }
     __syncthreads();
+    SORT_STAMP(3);
     const int grp = tid >> 7;                          // 8 groups of 128 threads
     bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+    SORT_STAMP(4);
     for (int t = tid; t < L; t += BK_THREADS) put(t, sk[t]);
+    SORT_STAMP(5);
   } else {   // longer than the LDS sorter: one composite-key network in global memory (slow, exact);
              // sentinels are the largest key and end up behind the L real ones
     bk_bitonic<false>(keys + s, LA, tid);
@@ -623,6 +643,13 @@ static inline int bk_grid(int64_t total, int64_t *chunk) {
 
 }  // namespace gsr
 
+#ifdef GSR_SORT_TIMELINE
+extern "C" int gsr_debug_set_sort_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_sort_timeline), &p, sizeof(p)));
+  return GSR_OK;
+}
+#endif
 #ifdef GSR_EMIT_TIMELINE
 extern "C" int gsr_debug_set_emit_timeline(void *buf) {
   unsigned long long *p = (unsigned long long *)buf;
