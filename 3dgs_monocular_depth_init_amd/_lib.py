@@ -32,8 +32,8 @@ SIGNATURES = {
     "gsr_tile_sort": [_i, _p, _p, _p, _p, _p, _p],
     "gsr_bucket_layout": [_i, _i, _i, _p, _p],
     "gsr_isect_scan_clear": [_i, _p, _p, _p, _p, _p],
-    "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p],
-    "gsr_bucket_emit": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _p],
+    "gsr_bucket_emit": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p],
     "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p],
     "gsr_pair_masks": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],

@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(BK_THREADS)
 bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
                     const int32_t *__restrict__ radii, int tile_w, int tile_h, int bw, int n_buckets,
                     int64_t chunk, int32_t *__restrict__ bucket_counts,
-                    int32_t *__restrict__ clear_a, int32_t *__restrict__ clear_b) {
+                    int32_t *__restrict__ clear_a, int32_t *__restrict__ clear_b,
+                    int32_t *__restrict__ wg_hist) {
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) hist[b] = 0;
   if (clear_a)
@@ -107,8 +108,12 @@ bucket_count_kernel(int C, int N, const float *__restrict__ means2d,
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS)
+  for (int b = threadIdx.x; b < n_buckets; b += BK_THREADS) {
     if (hist[b] > 0) atomicAdd(&bucket_counts[b], hist[b]);
+    // this workgroup's own counts, for the emit pass (same grid, same chunks): it reserves its ranges
+    // from them instead of walking its Gaussians a second time
+    if (wg_hist) wg_hist[(int64_t)blockIdx.x * n_buckets + b] = hist[b];
+  }
 }
 
 // Exclusive scan of a[0..n) in LDS by the whole workgroup (n <= 8192); returns the total.
@@ -179,7 +184,8 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
                    const int32_t *__restrict__ bucket_counts, int32_t *__restrict__ bucket_cursor,
                    int32_t *__restrict__ real_counts, int32_t *__restrict__ bucket_offsets,
                    int32_t *__restrict__ bucket_order, int32_t *__restrict__ tile_order,
-                   int32_t *__restrict__ total_host, uint64_t *__restrict__ keys, int64_t capacity) {
+                   int32_t *__restrict__ total_host, uint64_t *__restrict__ keys, int64_t capacity,
+                   const int32_t *__restrict__ wg_hist) {
   extern __shared__ int32_t lds[];
   int32_t *hist = lds, *base = lds + n_buckets, *resv = lds + 2 * n_buckets;
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
@@ -283,16 +289,20 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   }
   EMIT_STAMP(1);
   if (publisher) return;
-  for (int64_t gw = gw0; gw < g1; gw += UB * BK_THREADS) {
-    const int64_t gb = gw + lane;
-    if (gw != gw0) load_rects(gb);
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int64_t g = gb + (int64_t)u * BK_THREADS;
-      int x0, x1, y0, y1;
-      if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
-      for_each_bucket(C == 1 ? 0 : (int)(g / N), x0, x1, y0, y1, bw, tile_h,
-                      [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+  if (wg_hist) {   // the count pass left this workgroup's histogram behind (same grid, same chunks)
+    for (int b = tid; b < n_buckets; b += BK_THREADS) hist[b] = wg_hist[(int64_t)blockIdx.x * n_buckets + b];
+  } else {
+    for (int64_t gw = gw0; gw < g1; gw += UB * BK_THREADS) {
+      const int64_t gb = gw + lane;
+      if (gw != gw0) load_rects(gb);
+  #pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int64_t g = gb + (int64_t)u * BK_THREADS;
+        int x0, x1, y0, y1;
+        if (g >= g1 || !tile_rect_v(m2[u].x, m2[u].y, rd[u].x, rd[u].y, tile_w, tile_h, x0, x1, y0, y1)) continue;
+        for_each_bucket(C == 1 ? 0 : (int)(g / N), x0, x1, y0, y1, bw, tile_h,
+                        [&](int b, int xa, int xb, int) { atomicAdd(&hist[b], xb - xa); });
+      }
     }
   }
   __syncthreads();
@@ -667,7 +677,7 @@ extern "C" int gsr_bucket_layout(int C, int tile_w, int tile_h, int *bw_out, int
 
 extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii,
                                 int tile_w, int tile_h, int32_t *bucket_counts, int32_t *clear_a,
-                                int32_t *clear_b, int assume_zero, void *stream) {
+                                int32_t *clear_b, int assume_zero, int32_t *wg_hist, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && bucket_counts, "bucket_count: bad arguments");
   GSR_REQUIRE((clear_a == nullptr) == (clear_b == nullptr), "bucket_count: clear_a and clear_b go together");
   int bw, nb;
@@ -692,7 +702,7 @@ extern "C" int gsr_bucket_count(int C, int N, const float *means2d, const int32_
   const int grid = gsr::bk_grid(total, &chunk);
   hipLaunchKernelGGL(gsr::bucket_count_kernel, dim3(grid), dim3(gsr::BK_THREADS),
                      sizeof(int32_t) * nb, (hipStream_t)stream, C, N, means2d, radii, tile_w, tile_h,
-                     bw, nb, chunk, bucket_counts, clear_a, clear_b);
+                     bw, nb, chunk, bucket_counts, clear_a, clear_b, wg_hist);
   GSR_CHECK_LAUNCH("bucket_count");
   return GSR_OK;
 }
@@ -703,7 +713,7 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
                                const int32_t *bucket_counts, int32_t *bucket_cursor,
                                int32_t *real_counts, int32_t *bucket_offsets, int32_t *bucket_order,
                                int32_t *tile_order, int32_t *total_host, uint64_t *keys,
-                               int64_t capacity, void *stream) {
+                               int64_t capacity, const int32_t *wg_hist, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0 && tile_w > 0 && tile_h > 0 && capacity >= 0, "bucket_emit: bad sizes");
   int bw, nb;
   if (gsr_bucket_layout(C, tile_w, tile_h, &bw, &nb) != GSR_OK) {
@@ -723,12 +733,12 @@ extern "C" int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t
     hipLaunchKernelGGL(gsr::bucket_emit_kernel<true>, dim3(grid), dim3(gsr::BK_THREADS), lds,
                        (hipStream_t)stream, C, N, means2d, radii, depths, conics, opacities,
                        opac_per_camera, tile_w, tile_h, bw, nb, chunk, bucket_counts, bucket_cursor,
-                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity);
+                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity, wg_hist);
   else
     hipLaunchKernelGGL(gsr::bucket_emit_kernel<false>, dim3(grid), dim3(gsr::BK_THREADS), lds,
                        (hipStream_t)stream, C, N, means2d, radii, depths, conics, opacities,
                        opac_per_camera, tile_w, tile_h, bw, nb, chunk, bucket_counts, bucket_cursor,
-                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity);
+                       real_counts, bucket_offsets, bucket_order, tile_order, total_host, keys, capacity, wg_hist);
   GSR_CHECK_LAUNCH("bucket_emit");
   return GSR_OK;
 }

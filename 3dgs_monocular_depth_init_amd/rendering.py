@@ -378,7 +378,7 @@ def inverse4x4(mats: Tensor, translation_of: str = "inverse") -> Tuple[Tensor, T
 def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: int, tile_h: int,
                        want_tiles_per_gauss: bool = False, tile_counts: Optional[Tensor] = None,
                        capacity: Optional[int] = None, conics: Optional[Tensor] = None,
-                       opacities: Optional[Tensor] = None, tight: bool = False):
+                       opacities: Optional[Tensor] = None, tight: bool = False, want_keys: bool = True):
     """Returns (tile_offsets [n_tiles+1] int32, tile_order [n_tiles] int32 (longest list
     first), flatten_ids [I] int32, isect_keys [I] int64 (sorted per tile), tiles_per_gauss or
     None, pair_ids [I] int32 or None).
@@ -393,7 +393,7 @@ def isect_tiles_sorted(means2d: Tensor, radii: Tensor, depths: Tensor, tile_w: i
     with_pairs = conics is not None and opacities is not None
     if with_pairs and (tile_counts is None or tile_counts.numel() == 0) and not want_tiles_per_gauss \
             and bucket_layout_ok(C, N, tile_w, tile_h):
-        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity, conics, opacities, tight)
+        return _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity, conics, opacities, tight, want_keys)
     counted = tile_counts is not None and tile_counts.numel() == n_tiles and not want_tiles_per_gauss
     if not counted:
         tile_counts = torch.empty(n_tiles, dtype=torch.int32, device=dev)
@@ -454,6 +454,7 @@ class _IsectState:
     # counts are zero between frames (the sort kernel clears them), the other two rows are cleared
     # by the count kernel: no memset launches
     scratch: Dict[Tuple[int, int], Tensor] = {}
+    wg_hist: Dict[Tuple[int, int], Tensor] = {}   # [256, n_buckets]: per-workgroup counts, count pass -> emit pass
 
 
 class _PendingIsect:
@@ -471,7 +472,7 @@ class _PendingIsect:
 
 @torch.no_grad()
 def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[int], conics, opacities,
-                    tight: bool):
+                    tight: bool, want_keys: bool = True):
     """isect_bucket.hip: buckets of 8 tiles, LDS histograms, one LDS sort per bucket.
     With `capacity` the call never blocks: returns full-capacity buffers and a
     _PendingIsect to resolve after the consumer kernels have been launched."""
@@ -487,6 +488,9 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
     if sc is None:
         sc = _IsectState.scratch[key] = torch.zeros(3, n_buckets, dtype=torch.int32, device=dev)
     counts, cursor, real = sc[0], sc[1], sc[2]
+    wg = _IsectState.wg_hist.get(key)
+    if wg is None:
+        wg = _IsectState.wg_hist[key] = torch.empty(256, n_buckets, dtype=torch.int32, device=dev)
     per_cam = int(opacities.dim() == 2)
     n_host = _IsectState.pinned.get(dev.index)
     if n_host is None:
@@ -495,7 +499,7 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
         order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
         call("gsr_bucket_count", C, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), ptr(cursor),
-             ptr(real), 1, st)
+             ptr(real), 1, ptr(wg), st)
         if capacity is None:
             slots = int(counts.sum().item())             # blocking: first frame / explicit request
             cap = max(slots, 1)
@@ -503,7 +507,9 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         else:
             cap = max(int(capacity), 1)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        keys_sorted = torch.empty(cap, dtype=torch.int64, device=dev)
+        # gsplat's `isect_ids` (the sorted keys) are meta data only: nothing downstream reads them, and the
+        # training step does not ask for them (18 MB less to write per step at c4)
+        keys_sorted = torch.empty(cap, dtype=torch.int64, device=dev) if want_keys else None
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         pair_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         tile_offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
@@ -511,7 +517,7 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         # the two totals land in pinned host memory straight from the kernels: no copy launches
         call("gsr_bucket_emit", C, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities),
              per_cam, tile_w, tile_h, int(tight), ptr(counts), ptr(cursor), ptr(real), ptr(offsets),
-             ptr(order), None if EXACT_TILE_ORDER else ptr(tile_order), n_host.data_ptr(), ptr(keys), cap, st)
+             ptr(order), None if EXACT_TILE_ORDER else ptr(tile_order), n_host.data_ptr(), ptr(keys), cap, ptr(wg), st)
         call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(real), ptr(keys),
              ptr(keys_sorted), ptr(flatten_ids), ptr(pair_ids), ptr(tile_offsets),
              ptr(tile_order) if EXACT_TILE_ORDER else None, cap, ptr(counts), n_host.data_ptr() + 4, st)
@@ -523,8 +529,8 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
         raise
     if capacity is None:
         n_isects, _ = pending.resolve()
-        return (tile_offsets, tile_order, flatten_ids[:n_isects], keys_sorted[:n_isects], None,
-                pair_ids[:n_isects])
+        return (tile_offsets, tile_order, flatten_ids[:n_isects],
+                keys_sorted[:n_isects] if want_keys else None, None, pair_ids[:n_isects])
     return tile_offsets, tile_order, flatten_ids, keys_sorted, pending, pair_ids
 
 
@@ -633,6 +639,7 @@ def rasterization(
     _raw_activations: bool = False,
     _campos: Optional[Tensor] = None,
     _tight_tiles: bool = False,
+    _isect_ids: bool = True,
     **unsupported,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
@@ -646,6 +653,7 @@ def rasterization(
     `opacities` logits, i.e. the exp/sigmoid of runner.py:324-325 (and their
     backward) run inside the projection kernels; `_campos` [C,3] supplies the
     camera centres so that the view matrices need not be inverted again;
+    `_isect_ids=False` leaves `meta["isect_ids"]` (the sorted keys, meta data only) unwritten and None.
     `_tight_tiles=True` lists a (tile, Gaussian) pair only when some pixel of the tile can
     reach alpha >= 1/255 (exact ellipse test) instead of whenever gsplat's bounding rectangle
     touches the tile: identical image and gradients, `meta["flatten_ids"]` / `isect_offsets`
@@ -762,7 +770,7 @@ def rasterization(
         tile_offsets, tile_order, flatten_ids, isect_keys, tpg, pair_ids = isect_tiles_sorted(
             means2d.detach(), radii, depths.detach(), tile_w, tile_h, want_tiles_per_gauss=False,
             tile_counts=tile_counts, capacity=capacity, conics=conics.detach(),
-            opacities=opac.detach().contiguous(), tight=bool(_tight_tiles))
+            opacities=opac.detach().contiguous(), tight=bool(_tight_tiles), want_keys=bool(_isect_ids))
         render_colors, render_alphas, _last = _Rasterize.apply(
             means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, pair_ids,
             records if use_sh else None, rcfg)
@@ -770,7 +778,8 @@ def rasterization(
             break
         n_isects, overflowed = tpg.resolve()
         if not overflowed:
-            flatten_ids, isect_keys, tpg = flatten_ids[:n_isects], isect_keys[:n_isects], None
+            flatten_ids, tpg = flatten_ids[:n_isects], None
+            isect_keys = isect_keys[:n_isects] if isect_keys is not None else None
             pair_ids = pair_ids[:n_isects]
             break
         capacity = None        # rare: this frame outgrew the guess -> rebuild, blocking

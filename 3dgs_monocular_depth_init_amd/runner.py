@@ -132,7 +132,7 @@ def rasterize_splats(
         colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
         packed=cfg.packed, absgrad=cfg.absgrad, sparse_grad=cfg.sparse_grad,
         rasterize_mode=rasterize_mode, distributed=False, camera_model=cfg.camera_model,
-        _raw_activations=True, _campos=campos, _tight_tiles=cfg.tight_tiles, **kwargs,
+        _raw_activations=True, _campos=campos, _tight_tiles=cfg.tight_tiles, _isect_ids=False, **kwargs,
     )
     if masks is not None:
         render_colors[~masks] = 0

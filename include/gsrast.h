@@ -224,6 +224,8 @@ int gsr_bucket_count(int C, int N, const float *means2d, const int32_t *radii, i
                      int tile_h, int32_t *bucket_counts, int32_t *clear_a /* NULL or [n_buckets] */,
                      int32_t *clear_b /* NULL or [n_buckets] */,
                      int assume_zero /* 1: bucket_counts is already zero, no memset launch */,
+                     int32_t *wg_hist /* NULL or [256, n_buckets]: each workgroup's own counts, which
+                                         gsr_bucket_emit (same grid) then reserves from without a second walk */,
                      void *stream);
 int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                     const float *conics, const float *opacities, int opac_per_camera, int tile_w,
@@ -235,7 +237,7 @@ int gsr_bucket_emit(int C, int N, const float *means2d, const int32_t *radii, co
                     int32_t *tile_order /* out [n_tiles] or NULL: compositing work order, longest
                                            bucket first (gsr_bucket_sort can produce the tile-exact one) */,
                     int32_t *total_host /* NULL or host-visible: reserved slots */, uint64_t *keys,
-                    int64_t capacity, void *stream);
+                    int64_t capacity, const int32_t *wg_hist /* NULL or what gsr_bucket_count wrote */, void *stream);
 int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets,
                     const int32_t *bucket_order, const int32_t *real_counts, uint64_t *keys,
                     uint64_t *keys_sorted /* NULL or [capacity] */, int32_t *flatten_ids,

@@ -44,6 +44,8 @@ order = torch.empty(nb, dtype=torch.int32, device=dev)
 cap = 4_000_000
 keys = torch.empty(cap, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+wg = torch.empty(256, nb, dtype=torch.int32, device=dev)
+WG = os.environ.get("NO_WG_HIST") is None          # per-workgroup counts handed from count to emit
 res = {}
 for tight in (1, 0):
     ts = []
@@ -51,10 +53,10 @@ for tight in (1, 0):
         scratch.zero_()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        call("gsr_bucket_count", 1, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), ptr(cursor), ptr(real), 1, st)
+        call("gsr_bucket_count", 1, N, ptr(means2d), ptr(radii), tile_w, tile_h, ptr(counts), ptr(cursor), ptr(real), 1, ptr(wg) if WG else None, st)
         e1.record()
         call("gsr_bucket_emit", 1, N, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opac), 0, tile_w, tile_h,
-             tight, ptr(counts), ptr(cursor), ptr(real), ptr(offsets), ptr(order), None, None, ptr(keys), cap, st)
+             tight, ptr(counts), ptr(cursor), ptr(real), ptr(offsets), ptr(order), None, None, ptr(keys), cap, ptr(wg) if WG else None, st)
         e2.record()
         torch.cuda.synchronize()
         if it >= 5:
