@@ -290,7 +290,8 @@ bucket_emit_kernel(int C, int N, const float *__restrict__ means2d,
   EMIT_STAMP(1);
   if (publisher) return;
   if (wg_hist) {   // the count pass left this workgroup's histogram behind (same grid, same chunks)
-    for (int b = tid; b < n_buckets; b += BK_THREADS) hist[b] = wg_hist[(int64_t)blockIdx.x * n_buckets + b];
+    if (g0 < g1)   // (a workgroup without Gaussians -- an empty input launches no count pass -- keeps its zeros)
+      for (int b = tid; b < n_buckets; b += BK_THREADS) hist[b] = wg_hist[(int64_t)blockIdx.x * n_buckets + b];
   } else {
     for (int64_t gw = gw0; gw < g1; gw += UB * BK_THREADS) {
       const int64_t gb = gw + lane;
