@@ -106,12 +106,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // 48 KB of LDS) for the launches whose 128x128 grid would leave the chip underfilled -- M = 3349
 // tokens are 27 row tiles, so N = 1024 gives 216 workgroups for 256 CUs with nothing to overlap
 // with; twice as many half-size workgroups, three resident per CU, finish sooner.
-template <int ACT, bool CONV, int BNT>
+// BMT = 64 (with BNT = 64): a 64x64 tile, each wave ONE 32x32 MFMA tile, 32 KB of LDS -- for the launches that
+// have fewer 128-row workgroups than the chip has CUs (the 1/14-resolution maps: 3344 rows = 27 row tiles):
+// each workgroup there walks its whole K alone on its CU, so twice as many workgroups of half the size finish sooner.
+template <int ACT, bool CONV, int BNT, int BMT = BM>
 __global__ void __launch_bounds__(256, 2)
 gemm_kernel(GemmArgs p) {
+  constexpr int NAS = BMT / 32;     // A staging instructions per wave
+  constexpr int NI = BMT / 64;      // 32-row MFMA tiles per wave
   constexpr int NBS = BNT / 32;     // B staging instructions per wave
   constexpr int NJ = BNT / 64;      // 32-column MFMA tiles per wave
-  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BM + BNT) * BK];   // [buffer][A rows | B rows][k]
+  __shared__ __attribute__((aligned(1024))) h16 smem[2][(BMT + BNT) * BK];   // [buffer][A rows | B rows][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs; remap so that
@@ -122,17 +127,17 @@ gemm_kernel(GemmArgs p) {
     const int q = nwg >> 3, r = nwg & 7, x = wg & 7;
     wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (wg >> 3);
   }
-  const int m0 = (wg / nbx) * BM, n0 = (wg % nbx) * BNT;
+  const int m0 = (wg / nbx) * BMT, n0 = (wg % nbx) * BNT;
   const int lr = lane & 31, lh = lane >> 5;
 
   // staging: wave w, instruction i moves rows (4w + i)*8 .. +7 of A (NBS*w + i for B);
   // lane -> (row, physical chunk)
   const int srow = lane >> 3, pch = lane & 7;
-  const h16 *ga[4], *gb[NBS];
-  int pix_y[4], pix_x[4], lch[4];
+  const h16 *ga[NAS], *gb[NBS];
+  int pix_y[NAS], pix_x[NAS], lch[NAS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + srow;
+  for (int i = 0; i < NAS; ++i) {
+    const int r = (wave * NAS + i) * 8 + srow;
     lch[i] = (pch ^ ((r >> 1) & 7)) * 8;                 // logical chunk offset in halves
     const int m = min(m0 + r, p.M - 1);
     if (CONV) {
@@ -161,7 +166,7 @@ gemm_kernel(GemmArgs p) {
       tap_ok = tap < p.cKS * p.cKS;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NAS; ++i) {
       const h16 *src;
       if (CONV) {
         const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
@@ -170,26 +175,26 @@ gemm_kernel(GemmArgs p) {
       } else {
         src = ga[i] + k0;
       }
-      h16 *dA = &smem[buf][(wave * 4 + i) * 8 * BK];
+      h16 *dA = &smem[buf][(wave * NAS + i) * 8 * BK];
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dA, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NBS; ++i) {
-      h16 *dB = &smem[buf][BM * BK + (wave * NBS + i) * 8 * BK];
+      h16 *dB = &smem[buf][BMT * BK + (wave * NBS + i) * 8 * BK];
       __builtin_amdgcn_global_load_lds((glb_void *)(gb[i] + k0), (lds_void *)dB, 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][NJ];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment rows of this lane and their swizzle terms
-  const int ra0 = wm * 64 + lr, ra1 = ra0 + 32, rb0 = wn * (BNT / 2) + lr, rb1 = rb0 + 32;
+  const int ra0 = wm * (BMT / 2) + lr, ra1 = ra0 + 32, rb0 = wn * (BNT / 2) + lr, rb1 = rb0 + 32;
   const int xa0 = (ra0 >> 1) & 7, xa1 = (ra1 >> 1) & 7, xb0 = (rb0 >> 1) & 7, xb1 = (rb1 >> 1) & 7;
 
   const int nk = p.K / BK;
@@ -199,19 +204,23 @@ gemm_kernel(GemmArgs p) {
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * BK);
-    const h16 *sA = smem[buf], *sB = smem[buf] + BM * BK;
+    const h16 *sA = smem[buf], *sB = smem[buf] + BMT * BK;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int cl = 2 * s + lh;
       const half8 af0 = *reinterpret_cast<const half8 *>(sA + ra0 * BK + ((cl ^ xa0) << 3));
-      const half8 af1 = *reinterpret_cast<const half8 *>(sA + ra1 * BK + ((cl ^ xa1) << 3));
       const half8 bf0 = *reinterpret_cast<const half8 *>(sB + rb0 * BK + ((cl ^ xb0) << 3));
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf0, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc[1][0], 0, 0, 0);
-      if constexpr (NJ == 2) {
-        const half8 bf1 = *reinterpret_cast<const half8 *>(sB + rb1 * BK + ((cl ^ xb1) << 3));
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc[1][1], 0, 0, 0);
+      if constexpr (NI == 2) {
+        const half8 af1 = *reinterpret_cast<const half8 *>(sA + ra1 * BK + ((cl ^ xa1) << 3));
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf0, acc[1][0], 0, 0, 0);
+        if constexpr (NJ == 2) {
+          const half8 bf1 = *reinterpret_cast<const half8 *>(sB + rb1 * BK + ((cl ^ xb1) << 3));
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0, bf1, acc[0][1], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1, bf1, acc[1][1], 0, 0, 0);
+        }
+      } else {
+        static_assert(NI == 2 || NJ == 1, "the 64-row tile is built 64 columns wide");
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as above: not left to the barrier's lowering)
@@ -224,7 +233,7 @@ gemm_kernel(GemmArgs p) {
     const int n = n0 + wn * (BNT / 2) + j * 32 + lr;
     if (n >= p.N) {
       if (n < p.pad_to) {      // zero channels of the output map, written here instead of by a fill launch
-        const int mb0 = m0 + wm * 64 + i * 32 + 4 * lh;
+        const int mb0 = m0 + wm * (BMT / 2) + i * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb0 + (r & 3) + 8 * (r >> 2);
@@ -235,7 +244,7 @@ gemm_kernel(GemmArgs p) {
     }
     const float b = p.bias ? p.bias[n] : 0.f;
     const float g = p.gamma ? p.gamma[n] : 1.f;
-    const int mb = m0 + wm * 64 + i * 32 + 4 * lh;
+    const int mb = m0 + wm * (BMT / 2) + i * 32 + 4 * lh;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -248,7 +257,7 @@ gemm_kernel(GemmArgs p) {
     }
   };
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) emit(acc[i][j], i, j);
 }
@@ -1262,7 +1271,9 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
   // (gemm8p addresses its operands with 32-bit byte offsets)
   const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32);
-  if (fits32 && (force_core == 4 || (force_core == 0 && p.K >= 256 && b256 >= 112))) {
+  // (N <= 128 would leave half of every 256-wide tile idle: 40964 x 128 x 2880 takes 71 us there, 54 us on the
+  // 128 x 64 tiles)
+  if (fits32 && (force_core == 4 || (force_core == 0 && p.K >= 256 && b256 >= 112 && p.N > 128))) {
     const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
 #define GSR_GEMM4(A) hipLaunchKernelGGL((gemm8p_kernel<A, CONV>), grid, dim3(512), 0, st, p)
     switch (p.act) {
@@ -1286,6 +1297,27 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
     case ACT_SIGMOID: GSR_GEMM(ACT_SIGMOID, BNT_); break; \
     case ACT_TANH: GSR_GEMM(ACT_TANH, BNT_); break;       \
     default: GSR_GEMM(ACT_NONE, BNT_); break;             \
+  }
+  // few 128x64 workgroups: 64x64 tiles (twice the workgroups, each walks half the rows): the 1/14-resolution
+  // convolutions 33 -> 21 us each
+  static const int no_small = getenv("GSR_DN_GEMM_NO64") ? atoi(getenv("GSR_DN_GEMM_NO64")) : 0;   // bench knobs
+  static const int max64 = getenv("GSR_DN_GEMM_64_MAX") ? atoi(getenv("GSR_DN_GEMM_64_MAX")) : 450;
+  // (measured per shape, tools/depthnet_shapes.py: up to 450 workgroups of 128 x 64 the smaller tiles win or tie
+  // -- 3349 x 1024 x 1024 31 -> 24 us, 13376 x 256 x 3456 59 -> 55 us -- except at K = 9216: 140 -> 148 us)
+  // (and from 256 workgroups up only to K = 3584: 3349 x 1024 x 4096 takes 48.6 us on 128 x 64, 51.7 us on 64 x 64)
+  if (narrow && !no_small && b64 < max64 && p.K >= 512 && p.K <= (b64 < 256 ? 4608 : 3584)) {
+    const dim3 grid64((unsigned)gsr::ceil_div(p.N, 64), (unsigned)gsr::ceil_div(p.M, 64));
+#define GSR_GEMM64(A) hipLaunchKernelGGL((gemm_kernel<A, CONV, 64, 64>), grid64, dim3(256), 0, st, p)
+    switch (p.act) {
+      case ACT_GELU: GSR_GEMM64(ACT_GELU); break;
+      case ACT_RELU: GSR_GEMM64(ACT_RELU); break;
+      case ACT_SIGMOID: GSR_GEMM64(ACT_SIGMOID); break;
+      case ACT_TANH: GSR_GEMM64(ACT_TANH); break;
+      default: GSR_GEMM64(ACT_NONE); break;
+    }
+#undef GSR_GEMM64
+    GSR_CHECK_LAUNCH("dn_gemm64");
+    return GSR_OK;
   }
   if (narrow) {
     GSR_GEMM_ACT(64)
