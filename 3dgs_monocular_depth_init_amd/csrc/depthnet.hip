@@ -1271,9 +1271,10 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
   // (gemm8p addresses its operands with 32-bit byte offsets)
   const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32);
-  // (N <= 128 would leave half of every 256-wide tile idle: 40964 x 128 x 2880 takes 71 us there, 54 us on the
-  // 128 x 64 tiles)
-  if (fits32 && (force_core == 4 || (force_core == 0 && p.K >= 256 && b256 >= 112 && p.N > 128))) {
+  // (only where the 256-wide tiles are at least 7/8 full: N = 128 would leave half of every tile idle -- 40964 x
+  // 128 x 2880 takes 71 us there, 54 us on the 128 x 64 tiles --, N = 384 a quarter: 101 against 69 us)
+  const bool tiles_full = (int64_t)p.N * 8 >= (int64_t)gsr::ceil_div(p.N, 256) * 256 * 7;
+  if (fits32 && (force_core == 4 || (force_core == 0 && p.K >= 256 && b256 >= 112 && tiles_full))) {
     const dim3 grid((unsigned)gsr::ceil_div(p.N, 256), (unsigned)gsr::ceil_div(p.M, 256));
 #define GSR_GEMM4(A) hipLaunchKernelGGL((gemm8p_kernel<A, CONV>), grid, dim3(512), 0, st, p)
     switch (p.act) {

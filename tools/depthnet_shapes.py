@@ -2,6 +2,7 @@
 """List the GEMM / implicit-convolution launches of one Metric3D inference by shape (count, FLOP share),
 timing each distinct shape alone (20 launches, events): where the network's GEMM time goes."""
 import collections
+import os
 import importlib
 import json
 import sys
@@ -62,5 +63,8 @@ for key, e in seen.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("%s: %d distinct GEMM shapes, %.2f ms of GEMM launches per image (each shape timed alone)" % (bb, len(rows), tot / 1e3))
-for t, n, us, tf, desc in rows[:40]:
-    print("  %6.0f us total  %3d x %6.1f us  %6.0f TFLOP/s  %s" % (t, n, us, tf, desc))
+if os.environ.get("SHAPES_JSON"):
+    print(json.dumps({desc: [n, round(us, 2)] for t, n, us, tf, desc in rows}))
+else:
+    for t, n, us, tf, desc in rows[:40]:
+        print("  %6.0f us total  %3d x %6.1f us  %6.0f TFLOP/s  %s" % (t, n, us, tf, desc))
