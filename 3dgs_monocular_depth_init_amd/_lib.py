@@ -103,6 +103,7 @@ SIGNATURES.update({
     "gsr_dn_gru_gate": [_i64, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "gsr_dn_swiglu": [_i64, _i, _p, _i, _p, _i, _p],
     "gsr_dn_conv3_head": [_i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _i, _p],
+    "gsr_dn_conv_gemm2": [_i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "gsr_dn_depth_expectation": [_i64, _i, _p, _i, _f, _f, _f, _p, _i, _p],
     "gsr_dn_normal_head": [_i64, _p, _i, _p, _i, _p, _i, _p],
     "gsr_dn_convex_upsample": [_i, _i, _i, _p, _p, _i, _f, _f, _f, _p, _p, _p, _p],

@@ -56,6 +56,10 @@ struct GemmArgs {
   int cH, cW, cC, cKS, cPad;
   const h16 *zero_page;   // >= 16 bytes of zeros
   int pad_to;             // columns [N, pad_to) of out16 are written as zeros (the map's zero channels)
+  // CONV only: the map may be a VIRTUAL CONCATENATION -- channels [0, c_split) are read from A2 (row stride
+  // lda2), channels [c_split, cC) from A; c_split % 64 == 0, so a K-tile never straddles the seam
+  const h16 *A2;
+  int lda2, c_split;
 };
 
 // GELU with the erf of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 rounding
@@ -171,7 +175,9 @@ gemm_kernel(GemmArgs p) {
       if (CONV) {
         const int iy = pix_y[i] + ky - p.cPad, ix = pix_x[i] + kx - p.cPad;
         const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-        src = ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lch[i] : p.zero_page;
+        const bool second = c0 < p.c_split;                // wave-uniform: this K-tile's channels come from A2
+        src = ok ? (second ? p.A2 + ((int64_t)iy * p.cW + ix) * p.lda2 : p.A + ((int64_t)iy * p.cW + ix) * p.lda) + c0 + lch[i]
+                 : p.zero_page;
       } else {
         src = ga[i] + k0;
       }
@@ -381,7 +387,9 @@ gemm8p_kernel(GemmArgs p) {
       } else if (CONV) {
         const int iy = pix_y[h][j] + ky - p.cPad, ix = pix_x[h][j] + kx - p.cPad;
         const bool ok = tap_ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-        dn_dma_16B(ok ? p.A + ((int64_t)iy * p.cW + ix) * p.lda + c0 + lchs[j] : p.zero_page, d);
+        const bool second = c0 < p.c_split;
+        dn_dma_16B(ok ? (second ? p.A2 + ((int64_t)iy * p.cW + ix) * p.lda2 : p.A + ((int64_t)iy * p.cW + ix) * p.lda) + c0 + lchs[j]
+                      : p.zero_page, d);
       } else {
         dn_dma_16B_off(p.A + k0, ga[h][j], d);
       }
@@ -1377,6 +1385,38 @@ extern "C" int gsr_dn_conv_gemm(int H, int Wd, int C, const void *in, int ldi, i
   p.zero_page = (const h16 *)zero_page;
   GSR_REQUIRE(out16_pad_to <= ldo16 && out16_pad_to <= gsr::ceil_div(N, 64) * 64,
               "dn_conv_gemm: out16_pad_to %d (N %d, ldo16 %d)", out16_pad_to, N, ldo16);
+  p.pad_to = out16_pad_to;
+  return launch_gemm<true>(p, stream);
+}
+
+// gsr_dn_conv_gemm over a virtual concatenation: channels [0, c_split) of the input are read from `first`
+// (row stride ld_first), channels [c_split, C) from `in` (whose first c_split channels are never read). The
+// ConvGRU's convolutions take [h | x] and [r * h | x] this way: no copy of the hidden state into the
+// concatenated input (RAFTDepthNormalDPTDecoder5.py:318-330, torch.cat([h, x], dim=1)).
+extern "C" int gsr_dn_conv_gemm2(int H, int Wd, int C, const void *in, int ldi, const void *first, int ld_first,
+                                 int c_split, int KS, int N, int K_pad, const void *W, const float *bias, int act,
+                                 const void *residual16, int ldr16, void *out16, int ldo16, const void *zero_page,
+                                 int out16_pad_to, void *stream) {
+  GSR_REQUIRE(H > 0 && Wd > 0 && C > 0 && C % 64 == 0 && (KS == 1 || KS == 3) && N > 0 &&
+                  K_pad >= KS * KS * C && K_pad % gsr::dn::BK == 0 && c_split > 0 && c_split < C && c_split % 64 == 0,
+              "dn_conv_gemm2: bad sizes H=%d W=%d C=%d (C %% 64) c_split=%d KS=%d K_pad=%d", H, Wd, C, c_split, KS, K_pad);
+  GSR_REQUIRE(in && first && W && out16 && zero_page, "dn_conv_gemm2: null pointer");
+  GSR_REQUIRE((ldi % 8) == 0 && (ld_first % 8) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)first & 15) == 0 &&
+                  ((uintptr_t)W & 15) == 0 && ((uintptr_t)zero_page & 15) == 0,
+              "dn_conv_gemm2: 16-byte alignment of the maps, the weights and the zero page");
+  GSR_REQUIRE(act >= 0 && act <= 4, "dn_conv_gemm2: act %d", act);
+  GemmArgs p = {};
+  p.M = H * Wd; p.N = N; p.K = K_pad;
+  p.A = (const h16 *)in; p.lda = ldi; p.W = (const h16 *)W;
+  p.A2 = (const h16 *)first; p.lda2 = ld_first; p.c_split = c_split;
+  p.bias = bias;
+  p.residual16 = (const h16 *)residual16; p.ldr16 = ldr16;
+  p.out16 = (h16 *)out16; p.ldo16 = ldo16;
+  p.act = act;
+  p.cH = H; p.cW = Wd; p.cC = C; p.cKS = KS; p.cPad = KS / 2;
+  p.zero_page = (const h16 *)zero_page;
+  GSR_REQUIRE(out16_pad_to <= ldo16 && out16_pad_to <= gsr::ceil_div(N, 64) * 64,
+              "dn_conv_gemm2: out16_pad_to %d (N %d, ldo16 %d)", out16_pad_to, N, ldo16);
   p.pad_to = out16_pad_to;
   return launch_gemm<true>(p, stream);
 }

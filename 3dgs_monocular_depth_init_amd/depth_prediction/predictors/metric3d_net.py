@@ -138,6 +138,8 @@ class Metric3DNet:
         self._prep_encoder({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
         self._prep_decoder({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")})
         self._scratch: Dict[str, torch.Tensor] = {}
+        self.concat_free_gru = True     # ConvGRU inputs as virtual concatenations (False: copy h into the input map)
+        self._gru_bufs: Dict[tuple, tuple] = {}
         self.flop_count = None          # set to 0.0 to accumulate the dense FLOPs of the next calls
 
     # ------------------------------------------------------------------ weights
@@ -409,6 +411,43 @@ class Metric3DNet:
         G = self.gru[g]
         C = G["C"]
         Cin = G["Cin"]
+        zrl, ql = G["zr"], G["q"]
+        cin_p = getattr(zrl, "cin_p", Cin)          # channels the weights are laid out for (zero channels behind Cin)
+        if (self.concat_free_gru and C % 64 == 0 and cin_p % 64 == 0 and zrl.k == 9 * cin_p and ql.k == 9 * cin_p
+                and getattr(ql, "cin_p", Cin) == cin_p and h.t.data_ptr() % 16 == 0 and h.ld % 8 == 0):
+            # torch.cat([h, x]) / torch.cat([r * h, x]) as virtual concatenations (`gsr_dn_conv_gemm2`): the
+            # convolutions read h / r*h in place of the first C input channels -- no copy of the hidden state
+            # into the concatenated input, and the input map (zero channels behind Cin) is allocated once
+            key = (g, h.H, h.W)
+            bufs = self._gru_bufs.get(key)
+            if bufs is None:
+                hx = Map(h.H, h.W, Cin, self.dev, ld=max(cin_p, _cpad(Cin)))
+                hx.t.zero_()
+                bufs = self._gru_bufs[key] = (hx, Map(h.H, h.W, 2 * C, self.dev, zero=False),
+                                              Map(h.H, h.W, C, self.dev, zero=False), Map(h.H, h.W, C, self.dev, zero=False),
+                                              Map(h.H, h.W, C, self.dev, zero=False))
+            hx, zr, z, rh, q = bufs
+            c0 = C
+            for ch, produce in xs:
+                produce(hx.chan(c0, ch))
+                c0 += ch
+            assert c0 == Cin, (g, c0, Cin)
+            if getattr(self, "_zero_page", None) is None:
+                self._zero_page = torch.zeros(64, dtype=torch.float16, device=self.dev)
+            if self.flop_count is not None:
+                self.flop_count += 2.0 * h.P * (zrl.n + ql.n) * 9 * Cin
+
+            def conv2(first, lin, out):
+                call("gsr_dn_conv_gemm2", h.H, h.W, cin_p, ptr(hx.t), hx.ld, ptr(first.t), first.ld, C, 3, lin.n, lin.kp,
+                     ptr(lin.w), ptr(lin.b), ACT_NONE, None, 0, ptr(out.t), out.ld, ptr(self._zero_page), 0, _st())
+
+            conv2(h, zrl, zr)
+            call("gsr_dn_gru_gate", h.P, C, 0, ptr(zr.t), zr.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
+                 ptr(rh.t), rh.ld, _st())
+            conv2(rh, ql, q)
+            call("gsr_dn_gru_gate", h.P, C, 1, ptr(q.t), q.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
+                 None, 0, _st())
+            return
         hx = Map(h.H, h.W, Cin, self.dev)
         self.copy(h, hx.chan(0, C))
         c0 = C

@@ -581,6 +581,13 @@ int gsr_dn_conv_gemm(int H, int W, int C, const void *in, int ldi, int KS, int N
  * column order (tap * C + c); no im2col buffer, no GEMM tile of which 2 columns are used. */
 int gsr_dn_conv3_head(int H, int W, int C, const void *in, int ldi, int N, const void *Wt, int K_pad,
                       const float *bias, float *out32, int ldo, void *stream);
+/* gsr_dn_conv_gemm over a VIRTUAL CONCATENATION: channels [0, c_split) of the input come from `first` (row
+ * stride ld_first), channels [c_split, C) from `in`, whose first c_split channels are never read. c_split a
+ * multiple of 64. The ConvGRU's torch.cat([h, x]) / torch.cat([r * h, x]) (RAFTDepthNormalDPTDecoder5.py:318-330)
+ * without copying the hidden state into the concatenated input. */
+int gsr_dn_conv_gemm2(int H, int W, int C, const void *in, int ldi, const void *first, int ld_first, int c_split,
+                      int KS, int N, int K_pad, const void *Wt, const float *bias, int act, const void *residual16,
+                      int ldr16, void *out16, int ldo16, const void *zero_page, int out16_pad_to, void *stream);
 /* LayerNorm over the last dimension of [M,D] (fp32 or fp16 input), optional ReLU. */
 int gsr_dn_layernorm(int M, int D, const void *x, int ldx, int x_is_f16, const float *gamma,
                      const float *beta, float eps, void *out16, int ldo16, float *out32, int ldo32,

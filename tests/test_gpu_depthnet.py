@@ -454,3 +454,22 @@ def test_full_size_vitl_runs(N):
     assert d.shape == (1, 1, 616, 1064) and o["prediction_normal"].shape == (1, 4, 616, 1064)
     assert torch.isfinite(d).all() and torch.isfinite(c).all() and torch.isfinite(o["prediction_normal"]).all()
     assert float(d.min()) >= 0.1 and float(d.max()) <= 200.0
+
+
+def test_gru_virtual_concatenation_equals_copied_input(N):
+    """`gsr_dn_conv_gemm2` (the ConvGRU's [h | x] and [r*h | x] read as virtual concatenations, persistent
+    buffers) against the copy of h into the concatenated input map: the same values enter the same kernels,
+    so the decoder outputs are IDENTICAL."""
+    cfg = N.CONFIGS["vitl"]
+    net = N.Metric3DNet(_state(cfg), backbone="vitl", device="cuda", input_size=(112, 168), use_graph=False)
+    tok = torch.from_numpy(FG["vitl_tokens"]).half().cuda()
+    assert net.concat_free_gru
+    d1, c1, n1, i1 = net.decode(tok, return_intermediates=True)
+    assert len(net._gru_bufs) == 3                       # the path ran at all three levels
+    d1b, c1b, n1b = net.decode(tok)                      # and again on the now persistent buffers
+    net.concat_free_gru = False
+    d0, c0, n0, i0 = net.decode(tok, return_intermediates=True)
+    for a, b in zip(i1["deltas"], i0["deltas"]):
+        assert torch.equal(a, b)
+    assert torch.equal(d1, d0) and torch.equal(c1, c0) and torch.equal(n1, n0)
+    assert torch.equal(d1b, d0) and torch.equal(c1b, c0)
