@@ -702,6 +702,50 @@ layernorm_kernel(int M, int D, const TIN *__restrict__ x, int ldx, const float *
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const TIN *xr = x + (int64_t)row * ldx;
+  if constexpr (sizeof(TIN) == 4) {
+    // fp32 rows of 256 / 512 / 768 / 1024 elements (the encoder's token rows): four consecutive elements per
+    // lane and 256-element chunk -- float4 loads of x, gamma, beta, 8-byte fp16 stores: a quarter of the memory
+    // instructions of the element-per-lane form below (49 launches per ViT-L image, 11 -> 7 us each)
+    const bool vec = (D & 255) == 0 && D <= 1024 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+                     ((((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0 &&
+                     (!out16 || ((ldo16 & 3) == 0 && (((uintptr_t)out16) & 7) == 0)) &&
+                     (!out32 || ((ldo32 & 3) == 0 && (((uintptr_t)out32) & 15) == 0));
+    if (vec) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const int nc = D >> 8;
+      f4 v[4];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = (k < nc) ? *reinterpret_cast<const f4 *>(reinterpret_cast<const float *>(xr) + 4 * lane + 256 * k)
+                        : f4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      }
+      const float mean = wave_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nc) {
+          const f4 d = v[k] - mean;
+          q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+      const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nc) {
+          const int i = 4 * lane + 256 * k;
+          f4 y = (v[k] - mean) * rstd * *reinterpret_cast<const f4 *>(gamma + i) + *reinterpret_cast<const f4 *>(beta + i);
+          if (relu) y = f4{fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f)};
+          if (out16) {
+            half4 o;
+            o[0] = (h16)y.x; o[1] = (h16)y.y; o[2] = (h16)y.z; o[3] = (h16)y.w;
+            *reinterpret_cast<half4 *>(out16 + (int64_t)row * ldo16 + i) = o;
+          }
+          if (out32) *reinterpret_cast<f4 *>(out32 + (int64_t)row * ldo32 + i) = y;
+        }
+      return;
+    }
+  }
   if (D <= 1024) {   // the row is read ONCE: 16 elements per lane stay in registers for both moments
     float v[16];
     float s = 0.f;
