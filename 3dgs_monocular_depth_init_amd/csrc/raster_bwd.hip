@@ -163,15 +163,22 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
   GSR_WAIT_VMEM();
   dma_stage_batch_planes(records, sPw[0], lane, sRec[0]);
   int buf = 0, slot = 0, n_prev = 0;
+  TL_DECL();
   for (int batch_end = start; batch_end >= s; batch_end -= RBATCH, buf ^= 1, slot = (slot == 2) ? 0 : slot + 1) {
     const int n = min(RBATCH, batch_end - s + 1);
+    TL_MARK(3);        // (3) = everything outside the three segments below
     GSR_WAIT_VMEM();   // this batch's records and the next batch's words are in LDS
+    TL_MARK(0);        // (0) waiting for the staged batch
     const int s1 = (slot == 2) ? 0 : slot + 1, s2 = (s1 == 2) ? 0 : s1 + 1;   // s2 = previous batch's slot
     if (n_prev > 0) flush(n_prev, sRec[buf ^ 1], sPw[s2]);
     if (batch_end - RBATCH >= s) {
       dma_stage_batch_planes(records, sPw[s1], lane, sRec[buf ^ 1]);
       dma_pair_words<-1>(pair_ids, batch_end - 2 * RBATCH, s, start, lane, sPw[s2]);
     }
+    TL_MARK(1);        // (1) flushing the previous batch's rows (atomics) + issuing the next DMAs
+#ifdef GSR_RASTER_TIMELINE
+    ++tl_batches;
+#endif
     const float4(*rec)[RBATCH] = sRec[buf];
     const uint32_t pw = sPw[slot][lane & 31];   // lane j < n: pair j's word (mask in the top bits)
     // opacity > 0.999 somewhere in the batch (the pair words' clamp flags): alpha may hit the clamp
@@ -297,12 +304,15 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     } else {
       for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
     }
+    TL_MARK(2);        // (2) the compositing loop
     n_prev = n;
   }
   // the last batch's rows: its records are in sRec[buf ^ 1] (buf was flipped on the way out),
   // its words in the slot before `slot`
   GSR_WAIT_VMEM();
   flush(n_prev, sRec[buf ^ 1], sPw[(slot == 0) ? 2 : slot - 1]);
+  TL_MARK(1);
+  TL_STORE(1, tile, start - s + 1);
 }
 
 // Test hook for the lane-swap tree (the semantics of v_permlane{16,32}_swap are
@@ -384,3 +394,12 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
 #undef GSR_BWD_CASE
   return GSR_EINVAL;
 }
+
+#ifdef GSR_RASTER_TIMELINE
+// buf: [n_tiles, 8] uint64 on the device (or NULL to switch off)
+extern "C" int gsr_debug_set_bwd_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_raster_timeline), &p, sizeof(p), sizeof(p)));
+  return GSR_OK;
+}
+#endif

@@ -186,6 +186,35 @@ __device__ __forceinline__ void dma_4B(const void *src_lane, const void *lds_dst
 }
 #define GSR_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// Diagnostic build (-DGSR_RASTER_TIMELINE=1, tools/raster_timeline.py): per tile (= wave) the compositing
+// kernels add up shader-clock segments -- waiting for the staged batch, issuing the next DMAs (backward:
+// + flushing the previous batch's rows), the compositing loop -- into 8 words per tile of a side buffer.
+// The stamps serialise what the product kernel overlaps: read the SHARES, not the times.
+#ifdef GSR_RASTER_TIMELINE
+static __device__ unsigned long long *g_raster_timeline[2] = {nullptr, nullptr};   // [0] forward, [1] backward; one copy per translation unit
+__device__ __forceinline__ unsigned long long tl_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define TL_DECL() unsigned long long tl_seg[4] = {0, 0, 0, 0}, tl_t = tl_now(); const unsigned long long tl_t0 = tl_t; int tl_batches = 0
+#define TL_MARK(k) do { const unsigned long long n_ = tl_now(); tl_seg[k] += n_ - tl_t; tl_t = n_; } while (0)
+#define TL_STORE(which, tile, pairs)                                                         \
+  do {                                                                                       \
+    unsigned long long *b_ = g_raster_timeline[which];                                       \
+    if (b_ && threadIdx.x == 0) {                                                            \
+      b_ += 8 * (int64_t)(tile);                                                             \
+      b_[0] = tl_seg[0]; b_[1] = tl_seg[1]; b_[2] = tl_seg[2]; b_[3] = tl_seg[3];            \
+      b_[4] = tl_now() - tl_t0; b_[5] = (unsigned long long)tl_batches;                      \
+      b_[6] = (unsigned long long)(pairs); b_[7] = tl_t0;                                    \
+    }                                                                                        \
+  } while (0)
+#else
+#define TL_DECL()
+#define TL_MARK(k)
+#define TL_STORE(which, tile, pairs)
+#endif
+
 // Pair words travel through LDS too (a 3-slot ring of 32 words, filled two batches ahead): held in
 // registers across the compositing loop they were what the register allocator spilled first -- and
 // a spill of a just-loaded register is a wait for it. Slot (batch number % 3), word r = the batch's

@@ -88,6 +88,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   const int s = tile_offsets[tile], e = tile_offsets[tile + 1];
   const int last = e - 1;
   unsigned live = 0xfu;   // wave-uniform: quadrants that still have an unfinished pixel
+  TL_DECL();
   if (e > s) {
     // pipeline: pair words two batches ahead, records one batch ahead, both by LDS-DMA
     dma_pair_words<1>(pair_ids, s, s, last, lane, sPw[0]);
@@ -102,12 +103,18 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
         if (!__any(px[q] != PIX_DONE)) live &= ~(1u << q);
       if (live == 0) break;
       const int n = min(RBATCH, e - base);
+      TL_MARK(3);                            // (3) = everything outside the three segments below
       GSR_WAIT_VMEM();                       // this batch's records and the next batch's words are in LDS
+      TL_MARK(0);                            // (0) waiting for the staged batch
       if (base + RBATCH < e) {
         const int s1 = (slot == 2) ? 0 : slot + 1, s2 = (s1 == 2) ? 0 : s1 + 1;
         dma_stage_batch(records, sPw[s1], lane, sRec[buf ^ 1]);
         dma_pair_words<1>(pair_ids, base + 2 * RBATCH, s, last, lane, sPw[s2]);
       }
+      TL_MARK(1);                            // (1) issuing the next batch's DMAs
+#ifdef GSR_RASTER_TIMELINE
+      ++tl_batches;
+#endif
       const uint32_t pw = sPw[slot][lane & 31];   // lane j < n: pair j's word (mask in the top bits)
       // opacity > 0.999 somewhere in the batch (the pair words' clamp flags): alpha may hit the clamp
       const bool can_clamp = (lane < n) && (pw & PAIR_CLAMP_BIT);
@@ -165,9 +172,11 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
       } else {
         for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
       }
+      TL_MARK(2);                            // (2) the compositing loop
     }
     GSR_WAIT_VMEM();   // a DMA issued for a batch the early exit skipped must land before the wave ends
   }
+  TL_STORE(0, tile, e - s);
 
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -276,3 +285,12 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
 #undef GSR_FWD_CASE
   return GSR_EINVAL;
 }
+
+#ifdef GSR_RASTER_TIMELINE
+// buf: [n_tiles, 8] uint64 on the device (or NULL to switch off)
+extern "C" int gsr_debug_set_fwd_timeline(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_raster_timeline), &p, sizeof(p), 0));
+  return GSR_OK;
+}
+#endif
