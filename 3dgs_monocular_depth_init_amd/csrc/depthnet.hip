@@ -7,10 +7,15 @@
 // from depth_prediction/predictors/metric3d.py:87-88 (`model.inference`).
 //
 // Building blocks (all hand-written, no BLAS / MIOpen):
-//   gemm_kernel        C = epilogue(A[M,K] * W[N,K]^T): 128x128x64 tiles, 4 waves x (2x2) tiles of
-//                      v_mfma_f32_32x32x16_f16, LDS double buffer, fused bias / GELU / ReLU /
+//   gemm_kernel        C = epilogue(A[M,K] * W[N,K]^T): 128x128 / 128x64 / 64x64 tiles x K 64, 4 waves of
+//                      v_mfma_f32_32x32x16_f16 tiles, LDS-DMA double buffer, fused bias / GELU / ReLU /
 //                      sigmoid / tanh / layer-scale / residual epilogue. Every Linear, every 1x1
-//                      convolution (NHWC) and -- through im2col rows -- every 3x3 convolution.
+//                      convolution (NHWC) and every 3x3 convolution (taps gathered straight from the
+//                      map, optionally from a virtual concatenation of two maps).
+//   gemm8p_kernel      the same contract on a 256x256x64 tile in eight phases per two K-tiles (8 waves
+//                      of 128x64, v_mfma_f32_16x16x32_f16, half-tile staging seven phases ahead with one
+//                      counted wait per K-tile, epilogue through LDS): the launches that fill the chip.
+//   conv3_head_kernel  3x3 convolution with <= 8 output channels accumulated into an fp32 field.
 //   attention_kernel   flash-style softmax(QK^T/sqrt(d))V for head_dim 64: S^T = K Q^T on MFMA so
 //                      that a query is a LANE (softmax over keys = over the lane's registers + one
 //                      cross-half exchange), P stays in registers as the B operand of O^T += V^T P.
