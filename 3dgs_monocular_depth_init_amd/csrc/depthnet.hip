@@ -1318,7 +1318,11 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   // round) stays wide: 86 us against 116 us narrow.
   const int b128 = rows * gsr::ceil_div(p.N, 128), b64 = rows * gsr::ceil_div(p.N, 64);
   // (only where the rounding matters, up to two rounds: 8192^3 is 1390 us wide, 1560 us narrow)
-  const bool narrow = p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512);
+  // (N <= 64: one column tile either way, and the 64-wide one does half the MFMA work of the 128-wide --
+  // Metric3D-small's 48-channel maps)
+  static const int wide_small = getenv("GSR_DN_GEMM_WIDE_SMALL_N") ? atoi(getenv("GSR_DN_GEMM_WIDE_SMALL_N")) : 0;   // bench knob
+  const bool narrow = (p.N <= 64 && !wide_small) ||
+                      (p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512));
   // The 256x256 eight-phase core wherever its grid occupies the chip: from 112 workgroups (one round on
   // 256 CUs) up. Same box, plain fp16 GEMM, TFLOP/s (profiles/r03_depthnet_gemm.md): 3349x3072x1024
   // 459 -> 679, 3349x4096x1024 495 -> 860, 40964x256x2304 582 -> 811, 40964x512x2880 666 -> 908,
