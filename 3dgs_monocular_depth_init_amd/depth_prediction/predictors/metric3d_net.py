@@ -448,7 +448,11 @@ class Metric3DNet:
             call("gsr_dn_gru_gate", h.P, C, 1, ptr(q.t), q.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
                  None, 0, _st())
             return
-        hx = Map(h.H, h.W, Cin, self.dev)
+        # (channel counts that are not multiples of 64 -- Metric3D-small: the concatenated input is a real
+        # copy; its map is allocated and zeroed ONCE per level, every call overwrites all Cin channels)
+        hx = self._gru_bufs.get((g, h.H, h.W, "copy"))
+        if hx is None:
+            hx = self._gru_bufs[(g, h.H, h.W, "copy")] = Map(h.H, h.W, Cin, self.dev)
         self.copy(h, hx.chan(0, C))
         c0 = C
         for ch, produce in xs:
@@ -456,7 +460,8 @@ class Metric3DNet:
             c0 += ch
         assert c0 == Cin, (g, c0, Cin)
         zr = self.conv(hx, G["zr"], 3, Map(h.H, h.W, 2 * C, self.dev, zero=False))
-        z = Map(h.H, h.W, C, self.dev)
+        z = Map(h.H, h.W, C, self.dev, zero=False)                   # (only its C channels are ever read: no fill)
+        z.pad_pending = False
         call("gsr_dn_gru_gate", h.P, C, 0, ptr(zr.t), zr.ld, ptr(ctx.t), ctx.ld, ptr(h.t), h.ld, ptr(z.t), z.ld,
              ptr(hx.t), hx.ld, _st())                                # r*h overwrites the h slot of hx
         q = self.conv(hx, G["q"], 3, Map(h.H, h.W, C, self.dev, zero=False))
