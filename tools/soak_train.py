@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=1500)
 ap.add_argument("--gaussians", type=int, default=300_000)
 ap.add_argument("--grow-grad2d", type=float, default=0.0002)
+ap.add_argument("--mcmc", action="store_true", help="MCMCStrategy (relocation + growth to cap_max, noise, both regularisers)")
 args = ap.parse_args()
 runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
 D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
@@ -44,16 +45,23 @@ knn = importlib.import_module("3dgs_monocular_depth_init_amd.knn")
 splats, opts = runner.create_splats_with_optimizers(pts, torch.rand(n0, 3), knn.initial_log_scales(pts.cuda()).cpu(), init_opacity=0.3)
 fused = D.fuse_optimizers(splats, opts)
 fused.fuse_into_backward(True)
-strat = S.DefaultStrategy(refine_start_iter=100, refine_every=100, reset_every=700, refine_stop_iter=args.steps - 100, grow_grad2d=args.grow_grad2d)
-strat.check_sanity(splats, fused)
-st = strat.initialize_state(scene_scale=1.0)
+if args.mcmc:
+    strat = S.MCMCStrategy(cap_max=int(1.5 * n0), refine_start_iter=100, refine_every=100, refine_stop_iter=args.steps - 100)
+    strat.check_sanity(splats, fused)
+    st = strat.initialize_state()
+    reg = dict(opacity_reg=0.01, scale_reg=0.01)           # the "mcmc" preset (trainer.py:83-92)
+else:
+    strat = S.DefaultStrategy(refine_start_iter=100, refine_every=100, reset_every=700, refine_stop_iter=args.steps - 100, grow_grad2d=args.grow_grad2d)
+    strat.check_sanity(splats, fused)
+    st = strat.initialize_state(scene_scale=1.0)
+    reg = {}
 losses, counts = [], []
 t0 = time.perf_counter()
 try:
     for step in range(args.steps):
         i = (step * 7) % len(cams)
         loss, info = runner.train_step(splats, fused, c2ws[i:i + 1], Ks[i:i + 1], targets[i], step=step, strategy=strat,
-                                       strategy_state=st)
+                                       strategy_state=st, **reg)
         if step % 50 == 0 or step == args.steps - 1:
             losses.append(float(loss))
             counts.append(len(splats["means"]))
