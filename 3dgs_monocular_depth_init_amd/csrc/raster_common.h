@@ -175,6 +175,16 @@ __device__ __forceinline__ void dma_16B(const void *src_lane, const void *lds_ds
       : "v"(src_lane), "s"(dst)
       : "memory");
 }
+// the same with the non-temporal policy (once-read streams: the shN block of the projection forward)
+__device__ __forceinline__ void dma_16B_nt(const void *src_lane, const void *lds_dst_uniform) {
+  const uint32_t dst = lds_addr(lds_dst_uniform);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src_lane), "s"(dst)
+      : "memory");
+}
 __device__ __forceinline__ void dma_4B(const void *src_lane, const void *lds_dst_uniform) {
   const uint32_t dst = lds_addr(lds_dst_uniform);
   unsigned keep;
