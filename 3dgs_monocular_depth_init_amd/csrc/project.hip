@@ -118,7 +118,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   float mean[3] = {means[i * 3 + 0], means[i * 3 + 1], means[i * 3 + 2]};
   float q[4] = {quats[i * 4 + 0], quats[i * 4 + 1], quats[i * 4 + 2], quats[i * 4 + 3]};
   float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
-  float opac = opacities ? opacities[i] : -1.f;
+  float opac = opacities ? opacities[i] : -1.f;   // (non-temporal loads of these short rows: no gain, profiles/r03_ab_nt.log)
   // A1 fused (runner.py:324-325): scales = exp(raw), opacities = sigmoid(raw)
   if (activations & GSR_ACT_EXP_SCALES) {
     s[0] = expf(s[0]);
