@@ -85,7 +85,9 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   // AFTER the projection and lost to the band-wise reads below (0.101 -> 0.112 ms); those remain
   // for degrees 1 and 2, which need 9 or 24 of the 45 floats only.
   extern __shared__ __attribute__((aligned(16))) float sBand[];
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // last block first: the optimizer of the previous step wrote the parameters front to back, so the END of the
+  // arrays is what the caches still hold (walking front to back again would evict it before reaching it): -2.5 us
+  int64_t g = (int64_t)(gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= (int64_t)C * N) return;
   int c = (C == 1) ? 0 : (int)(g / N);   // (64-bit division only with several cameras)
   int i = (int)(g - (int64_t)c * N);
