@@ -91,13 +91,19 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   if (g >= (int64_t)C * N) return;
   int c = (C == 1) ? 0 : (int)(g / N);   // (64-bit division only with several cameras)
   int i = (int)(g - (int64_t)c * N);
+  // the wave's private slab: 64 x 45 floats when the launch prefetches whole rows, 64 x 21 (the widest band) otherwise
+  float *const wslab = &sBand[(threadIdx.x >> 6) * (64 * (prefetch_rows ? 45 : 21))];
   bool slab_ready = false;
   if (prefetch_rows) {
     const int lane = threadIdx.x & 63;
-    const bool whole = (i - lane >= 0) && (i - lane + 63 < N);
+    // all 64 rows exist, belong to this camera, and the block starts on a 16-byte boundary: the DMA moves
+    // 16-byte pieces, a row is 180 bytes, so the wave's first row must be a multiple of 4. With one camera it
+    // is a multiple of 64; with several it is 64 m - c N, i.e. misaligned whenever c N % 4 != 0 -- such waves
+    // take the band-wise reads below (dword accesses, no alignment requirement).
+    const bool whole = (i - lane >= 0) && (i - lane + 63 < N) && (((i - lane) & 3) == 0);
     slab_ready = whole;
     if (slab_ready) {
-      float *slab = &sBand[(threadIdx.x >> 6) * (64 * 45)];
+      float *slab = wslab;
       const float *src = shN + (int64_t)(i - lane) * 45;
 #pragma unroll
       for (int it = 0; it < 12; ++it) {
@@ -157,11 +163,11 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     float r = 0.f, gg = 0.f, b = 0.f;
     const int lane = threadIdx.x & 63;
     // every lane of the wave has a row of the same camera and the rows are the reference's 45 floats
-    const bool banded = !prefetch_rows && sh_degree > 0 && shN_stride == 45 && (i - lane >= 0) && (i - lane + 63 < N);
+    const bool banded = !slab_ready && sh_degree > 0 && shN_stride == 45 && (i - lane >= 0) && (i - lane + 63 < N);
     if (slab_ready) {
       GSR_WAIT_VMEM();
       if (p.rx > 0) {
-        const float *cn = &sBand[(threadIdx.x >> 6) * (64 * 45)] + lane * 45;
+        const float *cn = wslab + lane * 45;
         float dx = mean[0] - campos[c * 3 + 0];
         float dy = mean[1] - campos[c * 3 + 1];
         float dz = mean[2] - campos[c * 3 + 2];
@@ -176,7 +182,7 @@ project_fwd_kernel(int C, int N, const float *__restrict__ means, const float *_
       }
     } else if (banded) {
       if (__any(p.rx > 0)) {
-        float *slab = &sBand[(threadIdx.x >> 6) * (64 * 21)];
+        float *slab = wslab;
         const int64_t first = (int64_t)(i - lane);
         float dx = mean[0] - campos[c * 3 + 0];
         float dy = mean[1] - campos[c * 3 + 1];

@@ -58,59 +58,63 @@ out = {}
 H, W = 112, 168
 img = DW.image(H, W)
 torch.set_num_threads(8)
+FULL_ONLY = "--full-only" in sys.argv     # regenerate depthnet_full_golden.npz alone
+bins = torch.exp(torch.linspace(math.log(0.1), math.log(200), 256)).unsqueeze(0)
 with torch.no_grad():
-    # (a) reduced ViT: 128-d, 2 heads, 2 blocks
-    enc = vit(128, 2, 2)
-    feats, meta = enc(img)
-    out["vit128_tokens"] = feats[0][0].numpy()                               # [101,128] final-norm tokens
-    out["vit128_meta"] = np.array(meta, np.int64)
-    # (b) vit_large_reg block shapes (1024-d, 16 heads), 2 blocks
-    encL = vit(1024, 16, 2)
-    featsL, _ = encL(img)
-    out["vit1024_tokens"] = featsL[0][0].numpy().astype(np.float16)
-    # (c) reduced decoder on the tokens of (a)
-    cfg = NS(model=NS(decode_head=NS(in_channels=[128] * 4, use_cls_token=True, feature_channels=[32, 64, 128, 256],
-                                     decoder_channels=[16, 32, 64, 128, 128], up_scale=7,
-                                     hidden_channels=[16, 16, 16, 16], n_gru_layers=3, n_downsample=2, iters=3,
-                                     slow_fast_gru=True, num_register_tokens=4)),
-             data_basic=NS(depth_normalize=(0.1, 200)))
-    dec = D.RAFTDepthNormalDPT5(cfg).eval()
-    dec.load_state_dict(DW.fill(dec))
-    bins = torch.exp(torch.linspace(math.log(0.1), math.log(200), 256)).unsqueeze(0)
-    dec.register_buffer("depth_expectation_anchor", bins, persistent=False)
-    # intermediates through the module's own sub-blocks (for localising a mismatch)
-    B, gh, gw, _, _, nreg = meta
-    vf = [[ft[:, 1 + nreg:, :].view(B, gh, gw, 128), ft[:, 0:1 + nreg, :].view(B, 1, 1, 128 * (1 + nreg))] for ft in feats]
-    ef = dec.token2feature(vf)
-    for i, t in enumerate(ef):
-        out[f"dec_encfeat{i}"] = t[0].permute(1, 2, 0).numpy().astype(np.float16)      # NHWC
-    ref_feat = dec.decoder_mono(ef)
-    out["dec_ref_feat"] = ref_feat[0].permute(1, 2, 0).numpy().astype(np.float16)
-    # heads and context encoder on a fresh copy of the features (decoder_mono rectified `ef`
-    # in place, exactly what the full forward below hands to the context encoder)
-    fmap = ref_feat[:, :-2]
-    dpred, _ = dec.regress_depth(fmap)
-    npred = dec.pred_normal(fmap, ref_feat[:, -1:])
-    depth_init = torch.cat((dpred, ref_feat[:, -2:-1], npred), dim=1)
-    out["dec_depth_init"] = depth_init[0].permute(1, 2, 0).numpy()                       # [H4, W4, 6]
-    cnet = dec.context_feature_encoder(ef[::-1])
-    for i, pair in enumerate(cnet):
-        out[f"dec_net{i}"] = torch.tanh(pair[0])[0].permute(1, 2, 0).numpy().astype(np.float16)
-        out[f"dec_ctx{i}"] = dec.context_zqr_convs[i](torch.relu(pair[1]))[0].permute(1, 2, 0).numpy().astype(np.float16)
-    deltas = []
-    hook = dec.update_block.register_forward_hook(
-        lambda m, i, o: deltas.append(o[2][0].permute(1, 2, 0).numpy()) if isinstance(o, tuple) and len(o) == 3 else None)
-    o = dec([feats, meta])
-    hook.remove()
-    for i, dl in enumerate(deltas):
-        out[f"dec_delta{i}"] = dl
-    out["dec_depth"] = o["prediction"][0, 0].numpy()
-    out["dec_conf"] = o["confidence"][0, 0].numpy()
-    out["dec_normal"] = o["prediction_normal"][0].numpy()
-    for k in ("dec_depth", "dec_conf", "dec_normal", "dec_ref_feat", "vit128_tokens", "vit1024_tokens"):
-        print(k, out[k].shape, float(np.abs(out[k].astype(np.float32)).mean()), float(np.abs(out[k].astype(np.float32)).max()))
-np.savez_compressed(HERE / "depthnet_golden.npz", **out)
-print("wrote depthnet_golden.npz")
+  if not FULL_ONLY:
+      # (a) reduced ViT: 128-d, 2 heads, 2 blocks
+      enc = vit(128, 2, 2)
+      feats, meta = enc(img)
+      out["vit128_tokens"] = feats[0][0].numpy()                               # [101,128] final-norm tokens
+      out["vit128_meta"] = np.array(meta, np.int64)
+      # (b) vit_large_reg block shapes (1024-d, 16 heads), 2 blocks
+      encL = vit(1024, 16, 2)
+      featsL, _ = encL(img)
+      out["vit1024_tokens"] = featsL[0][0].numpy().astype(np.float16)
+      # (c) reduced decoder on the tokens of (a)
+      cfg = NS(model=NS(decode_head=NS(in_channels=[128] * 4, use_cls_token=True, feature_channels=[32, 64, 128, 256],
+                                       decoder_channels=[16, 32, 64, 128, 128], up_scale=7,
+                                       hidden_channels=[16, 16, 16, 16], n_gru_layers=3, n_downsample=2, iters=3,
+                                       slow_fast_gru=True, num_register_tokens=4)),
+               data_basic=NS(depth_normalize=(0.1, 200)))
+      dec = D.RAFTDepthNormalDPT5(cfg).eval()
+      dec.load_state_dict(DW.fill(dec))
+      bins = torch.exp(torch.linspace(math.log(0.1), math.log(200), 256)).unsqueeze(0)
+      dec.register_buffer("depth_expectation_anchor", bins, persistent=False)
+      # intermediates through the module's own sub-blocks (for localising a mismatch)
+      B, gh, gw, _, _, nreg = meta
+      vf = [[ft[:, 1 + nreg:, :].view(B, gh, gw, 128), ft[:, 0:1 + nreg, :].view(B, 1, 1, 128 * (1 + nreg))] for ft in feats]
+      ef = dec.token2feature(vf)
+      for i, t in enumerate(ef):
+          out[f"dec_encfeat{i}"] = t[0].permute(1, 2, 0).numpy().astype(np.float16)      # NHWC
+      ref_feat = dec.decoder_mono(ef)
+      out["dec_ref_feat"] = ref_feat[0].permute(1, 2, 0).numpy().astype(np.float16)
+      # heads and context encoder on a fresh copy of the features (decoder_mono rectified `ef`
+      # in place, exactly what the full forward below hands to the context encoder)
+      fmap = ref_feat[:, :-2]
+      dpred, _ = dec.regress_depth(fmap)
+      npred = dec.pred_normal(fmap, ref_feat[:, -1:])
+      depth_init = torch.cat((dpred, ref_feat[:, -2:-1], npred), dim=1)
+      out["dec_depth_init"] = depth_init[0].permute(1, 2, 0).numpy()                       # [H4, W4, 6]
+      cnet = dec.context_feature_encoder(ef[::-1])
+      for i, pair in enumerate(cnet):
+          out[f"dec_net{i}"] = torch.tanh(pair[0])[0].permute(1, 2, 0).numpy().astype(np.float16)
+          out[f"dec_ctx{i}"] = dec.context_zqr_convs[i](torch.relu(pair[1]))[0].permute(1, 2, 0).numpy().astype(np.float16)
+      deltas = []
+      hook = dec.update_block.register_forward_hook(
+          lambda m, i, o: deltas.append(o[2][0].permute(1, 2, 0).numpy()) if isinstance(o, tuple) and len(o) == 3 else None)
+      o = dec([feats, meta])
+      hook.remove()
+      for i, dl in enumerate(deltas):
+          out[f"dec_delta{i}"] = dl
+      out["dec_depth"] = o["prediction"][0, 0].numpy()
+      out["dec_conf"] = o["confidence"][0, 0].numpy()
+      out["dec_normal"] = o["prediction_normal"][0].numpy()
+      for k in ("dec_depth", "dec_conf", "dec_normal", "dec_ref_feat", "vit128_tokens", "vit1024_tokens"):
+          print(k, out[k].shape, float(np.abs(out[k].astype(np.float32)).mean()), float(np.abs(out[k].astype(np.float32)).max()))
+if not FULL_ONLY:
+    np.savez_compressed(HERE / "depthnet_golden.npz", **out)
+    print("wrote depthnet_golden.npz")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -138,7 +142,9 @@ with torch.no_grad():
                                          iters=c["iters"], slow_fast_gru=True, num_register_tokens=4)),
                  data_basic=NS(depth_normalize=(0.1, 200)))
         dec = D.RAFTDepthNormalDPT5(cfg).eval()
-        dec.load_state_dict(DW.fill(dec))
+        # (round 4: depth channel of the update head rescaled so that the depth map is not clamp-saturated,
+        # dn_weights.FULL_DEPTH_GAIN)
+        dec.load_state_dict(DW.fill(dec, depth_gain=DW.FULL_DEPTH_GAIN))
         dec.register_buffer("depth_expectation_anchor", bins, persistent=False)
         deltas = []
         hook = dec.update_block.register_forward_hook(
@@ -146,6 +152,8 @@ with torch.no_grad():
         o = dec([feats, meta])
         hook.remove()
         assert len(deltas) == c["iters"]
+        dd = o["prediction"][0, 0]
+        assert float(dd.min()) > 0.2 and float(dd.max()) < 199.0, "depth map touches the clamp"
         full[f"{name}_delta_last"] = deltas[-1]
         full[f"{name}_depth"] = o["prediction"][0, 0].numpy()
         full[f"{name}_conf"] = o["confidence"][0, 0].numpy()

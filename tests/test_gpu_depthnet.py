@@ -303,10 +303,11 @@ SMALL_CFG = dict(embed_dim=128, depth=2, heads=2, feature_channels=[32, 64, 128,
                  decoder_channels=[16, 32, 64, 128, 128], hidden=[16, 16, 16, 16], iters=3)
 
 
-def _state(cfg):
+def _state(cfg, depth_gain=None):
     sd = {"encoder." + k: v for k, v in DW.fill(_vit_shapes(cfg["embed_dim"], cfg["depth"])).items()}
     sd.update({"decoder." + k: v for k, v in DW.fill(_dec_shapes(cfg["embed_dim"], cfg["feature_channels"],
-                                                                 cfg["decoder_channels"], cfg["hidden"])).items()})
+                                                                 cfg["decoder_channels"], cfg["hidden"]),
+                                                     depth_gain=depth_gain).items()})
     return sd
 
 
@@ -394,7 +395,7 @@ def test_full_depth_networks_vs_reference_golden(N, name):
     on the 112x168 input the CPU generator affords. 24 residual blocks and 8 recurrent refinements are
     where fp16 drift would accumulate; the 2-block fixtures cannot show it."""
     cfg = N.CONFIGS[name]
-    net = N.Metric3DNet(_state(cfg), backbone=name, device="cuda", input_size=(112, 168))
+    net = N.Metric3DNet(_state(cfg, depth_gain=DW.FULL_DEPTH_GAIN), backbone=name, device="cuda", input_size=(112, 168))
     tokens = net.encode(DW.image(112, 168))
     assert tokens.shape == (101, cfg["embed_dim"])
     _close(tokens, FG[f"{name}_tokens"].astype(np.float32), max_frac=6e-3, mean_frac=4e-3, what=f"{name} tokens")
@@ -406,25 +407,26 @@ def test_full_depth_networks_vs_reference_golden(N, name):
            what=f"{name} delta_flow[{cfg['iters'] - 1}]")
     _close(conf[0, 0], FG[f"{name}_conf"], max_frac=1e-2, mean_frac=6e-3, what=f"{name} confidence")
     _close(normal[0], FG[f"{name}_normal"], max_frac=1e-2, mean_frac=6e-3, what=f"{name} normal")
-    # depth: with random weights the recurrent updates push most pixels into the [0.1, 200] clamp;
-    # compared where the reference is not saturated (and the saturated set must agree)
+    # depth (round 4): the fixture's update head keeps BOTH networks' depth inside the (0.1, 200) clamp on every
+    # pixel (dn_weights.FULL_DEPTH_GAIN; round 3's ViT-L map was 99.5 % saturated and never compared), so the
+    # whole map -- accumulated updates, convex 4x upsampling, 100 * flow + 200, clamp -- is compared with a
+    # MAXIMUM bound. depth = 100 * flow + 200: an absolute flow error of 1e-2 of max|delta| (the bound on
+    # delta_flow above) would be 1 depth unit; recorded (profiles/parity_r04.json): 0.03-0.04 units maximum =
+    # 2.6e-4 of the map's maximum (5e-4 relative per pixel), mean 1e-4; the bounds are ~3x that.
     ref_d = torch.from_numpy(FG[f"{name}_depth"])
     got_d = depth[0, 0].float().cpu()
-    free = ref_d < 199.0
-    assert float(((got_d >= 199.0) != ~free).float().mean()) <= 5e-3
-    if int(free.sum()) > 100:
-        rel = ((got_d - ref_d).abs() / ref_d)[free]
-        from tests import parity_log
-        p999 = float(torch.quantile(rel, 0.999))
-        parity_log.record("depthnet", what=f"{name} depth (unsaturated)", pixels=int(free.sum()),
-                          max_rel_err=float(rel.max()), p999_rel_err=p999, mean_rel_err=float(rel.mean()))
-        # (the final depth is an exponential of the accumulated updates, times a convex upsampling
-        # of a [0.1, 200]-clamped map: a pixel next to a saturated neighbour can move by tens of
-        # per cent when that neighbour crosses the clamp; hence a quantile, not the maximum)
-        assert float(rel.mean()) <= 5e-3 and p999 <= 5e-2
+    assert float(ref_d.min()) > 0.2 and float(ref_d.max()) < 199.0          # nothing of the reference in the clamp
+    assert float(got_d.min()) > 0.2 and float(got_d.max()) < 199.0
+    rel = (got_d - ref_d).abs() / ref_d
+    from tests import parity_log
+    parity_log.record("depthnet", what=f"{name} depth (whole map, unsaturated)", pixels=rel.numel(),
+                      max_rel_err=float(rel.max()), p999_rel_err=float(torch.quantile(rel, 0.999)),
+                      mean_rel_err=float(rel.mean()), ref_min=float(ref_d.min()), ref_max=float(ref_d.max()))
+    _close(got_d, ref_d, max_frac=1e-3, mean_frac=4e-4, what=f"{name} depth")
     # and the whole chain, encoder into decoder
     d2, c2, o2 = net.inference({"input": DW.image(112, 168)})
     _close(c2[0, 0], FG[f"{name}_conf"], max_frac=2e-2, mean_frac=1e-2, what=f"{name} e2e confidence")
+    _close(d2[0, 0], ref_d, max_frac=1.5e-3, mean_frac=8e-4, what=f"{name} e2e depth")
 
 
 def test_vit_giant_swiglu_blocks_vs_reference_golden(N):

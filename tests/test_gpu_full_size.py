@@ -190,40 +190,193 @@ def test_c5_ranges_sorted_lists_and_linearity(R):
         assert rel < 1e-4, f"{k}: {rel:.2e}"
 
 
-def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000):
+def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_path=False):
+    """Oracle (CPU, ONE run) against the HIP path on camera 25's window of the 1080p frame.
+
+    default path: `rendering.rasterization` with gsplat's rectangle-rule lists and activated inputs.
+    timed_path=True ALSO runs the configuration bench.py times -- `runner.rasterize_splats`: raw
+    log-scales / logit opacities with exp / sigmoid and their chain rule inside the projection
+    kernels, `RasterConfig(tight_tiles=True)` lists, no `flatten_ids` -- on the same scene, and
+    checks it against the same oracle run: images as before, gradients w.r.t. the RAW parameters
+    against autograd through torch.exp / torch.sigmoid + the oracle (the pattern of
+    test_gpu_rasterization.py::test_runner_rasterize_splats_fused_activations, at c2 / c5 scale)."""
     import time
-    from tests.test_gpu_rasterization import _check, _run_both
+    from oracle import rasterization_oracle as O
+    from tests.test_gpu_rasterization import _check
     Rm = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
     sc = scenes.make_scene(n_gauss, 0)
     vm, K = scenes.cameras([25])
     K = K.clone()
     K[0, 0, 2], K[0, 1, 2] = cx, cy
+    names = ["means", "quats", "scales", "opacities", "sh0", "shN"]
+    raw = dict(sc, scales=torch.log(sc["scales"]), opacities=torch.logit(sc["opacities"]))
     t0 = time.perf_counter()
-    out = _run_both(Rm, sc, vm, K, width, height, split=True)
-    print(f"{n_gauss} Gaussians, view {width}x{height}: oracle + HIP fwd+bwd {time.perf_counter() - t0:.1f} s")
+    # oracle: raw leaves -> exp / sigmoid (autograd) -> oracle; the activated intermediates keep their
+    # gradients too, so one backward serves both comparisons
+    cpu_raw = {k: raw[k].clone().requires_grad_(True) for k in names}
+    act = dict(cpu_raw, scales=torch.exp(cpu_raw["scales"]), opacities=torch.sigmoid(cpu_raw["opacities"]))
+    act["scales"].retain_grad()
+    act["opacities"].retain_grad()
+    out_c = O.rasterization(act["means"], act["quats"], act["scales"], act["opacities"],
+                            torch.cat([act["sh0"], act["shN"]], 1), vm, K, width, height, sh_degree=sh_degree)
+    g = torch.Generator().manual_seed(11)
+    w_c, w_a = torch.randn(out_c[0].shape, generator=g), torch.randn(out_c[1].shape, generator=g)
+    ((out_c[0] * w_c).sum() + (out_c[1] * w_a).sum()).backward()
+    t_oracle = time.perf_counter() - t0
+
+    def hip(run):
+        rc, ra, meta = run()
+        meta["means2d"].retain_grad()
+        ((rc * w_c.cuda()).sum() + (ra * w_a.cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        return rc, ra, meta
+
     # ~40 fp32 terms per pixel: the mean error sits at 1e-6, the per-pixel bound stays 1e-4.
     # Threshold flips (a pair within rounding of alpha = 1/255 blended by one side only; sigma
     # is evaluated in a different but equivalent order here) touch ~12 of the 100 k Gaussians
     # at the full frame, i.e. 1.2e-4 of the gradient elements: allowed fraction 2e-4.
-    _check(*out, mean_frac=5e-2, flip_frac=2e-4)
+    # (a) default lists, activated inputs
+    gpu = {k: act[k].detach().clone().cuda().requires_grad_(True) for k in names}
+    out_g = hip(lambda: Rm.rasterization(gpu["means"], gpu["quats"], gpu["scales"], gpu["opacities"],
+                                         (gpu["sh0"], gpu["shN"]), vm.cuda(), K.cuda(), width, height,
+                                         sh_degree=sh_degree, packed=False))
+    _check(act, gpu, out_c, out_g, mean_frac=5e-2, flip_frac=2e-4)
+    if timed_path:
+        # (b) the timed configuration: raw parameters, tight lists, through runner.rasterize_splats
+        gpu_raw = torch.nn.ParameterDict({k: torch.nn.Parameter(raw[k].clone().cuda()) for k in names})
+        cfg = runner.RasterConfig(sh_degree=3, tight_tiles=True)
+        out_r = hip(lambda: runner.rasterize_splats(gpu_raw, torch.linalg.inv(vm).cuda(), K.cuda(), width, height,
+                                                    cfg, sh_degree=sh_degree))
+        _check(cpu_raw, gpu_raw, out_c, out_r, mean_frac=5e-2, flip_frac=2e-4)
+    print(f"{n_gauss} Gaussians, view {width}x{height}, SH degree {sh_degree}: oracle fwd+bwd {t_oracle:.1f} s, "
+          f"total {time.perf_counter() - t0:.1f} s")
 
 
 def test_c2_window_vs_oracle():
     """BASELINE config c2 (100 k Gaussians, camera 25 of the 1080p rig) against the CPU oracle,
     forward and backward, on a 512x512 window of the frame (principal point shifted, same
     focal length): footprints and list lengths are those of the full frame, the oracle's
-    tile loop is 8x shorter."""
-    _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0)
+    tile loop is 8x shorter. Both the gsplat-rule path and the configuration bench.py times."""
+    _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0, timed_path=True)
+
+
+@pytest.mark.parametrize("sh_degree", [0, 1, 2])
+def test_c2_window_vs_oracle_lower_sh_degrees(sh_degree):
+    """The same window at the SH degrees steps 0-2999 of every training run use (runner.py:464): degrees 1
+    and 2 read shN band-wise (a different code path from degree 3's LDS-DMA slab), degree 0 reads sh0 only;
+    the unused bands must receive exactly zero gradient. Both paths, as above."""
+    _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0, sh_degree=sh_degree, timed_path=True)
 
 
 def test_c5_window_vs_oracle():
     """BASELINE config c5's Gaussian side (2 M Gaussians) against the CPU oracle, forward and
     backward, on a 384x384 window of the 1080p frame (oracle time 1-3 min depending on the box's
-    host share; 512x512 took up to 5.6 min on a contended box)."""
-    _c2_vs_oracle(384, 384, 960.0 - 704.0, 540.0 - 284.0, n_gauss=2_000_000)
+    host share; 512x512 took up to 5.6 min on a contended box). Both the gsplat-rule path and the
+    configuration bench.py times (raw parameters + tight lists through runner.rasterize_splats)."""
+    _c2_vs_oracle(384, 384, 960.0 - 704.0, 540.0 - 284.0, n_gauss=2_000_000, timed_path=True)
 
 
 def test_c2_one_view_full_size_vs_oracle():
     """The same at the real 1920x1080: one full c2 view against the CPU oracle (1.5-5 min of oracle
     time on the GPU box's 16 host threads, depending on the box's host share)."""
-    _c2_vs_oracle(W, H, 960.0, 540.0)
+    _c2_vs_oracle(W, H, 960.0, 540.0, timed_path=True)
+
+
+def test_c4_fused_adam_backward_equals_backward_then_adam_step():
+    """`gsr_project_bwd_adam` (optimizer in backward: what bench.py's headline step runs) against
+    `gsr_project_bwd` + `gsr_adam_step` at c4's full size (1 M Gaussians, 1080p, SH degree 3), two steps.
+
+    The compositing backward's float atomics are order-nondeterministic, so two complete steps never see
+    bit-identical gradient rows. Here ONE real step produces the [N,16] rows (L1 loss against the seeded
+    noise target, tight lists, raw parameters -- the bench's configuration); both variants then consume
+    that SAME buffer through the projection backward's autograd node, so every difference left is the
+    fused kernel itself: parameters and both Adam moments of all 59 M elements must agree to rounding."""
+    Rm = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    losses = importlib.import_module("3dgs_monocular_depth_init_amd.losses")
+    N = 1_000_000
+    sc = scenes.make_scene(N, 0)
+    vm, K = scenes.cameras([3])
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def fresh():
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        return splats, D.fuse_optimizers(splats, opts)
+
+    # one real step's gradient rows: the buffer the compositing backward hands to the projection backward
+    seen = []
+    orig = Rm._rows_from_grads
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        seen.append(out)
+        return out
+
+    Rm._rows_from_grads = spy
+    request_restore = lambda: setattr(Rm, "_rows_from_grads", orig)
+    try:
+        splats, _ = fresh()
+        rc, _, info = runner.rasterize_splats(splats, c2w, K, W, H, runner.RasterConfig(), sh_degree=3)
+        losses.l1_loss(rc, target).backward()
+        rows, fast = seen.pop()
+        assert fast and rows.shape == (N, 16)
+        rows = rows.clone()
+    except BaseException:
+        request_restore()
+        raise
+    vis = (info["radii"][0] > 0).all(-1)
+    assert int(vis.sum()) > 800_000 and float(rows[:, :9].abs().max()) > 0
+    del rc, info, splats
+
+    viewmats, campos = Rm.inverse4x4(c2w, translation_of="input")
+    cfg = (W, H, 0.3, 0.01, 1e10, 0.0, False, 3, 3, -1, Rm.ACT_EXP_SCALES | Rm.ACT_SIGMOID_OPAC, 0, 0)
+
+    def run(fuse):
+        splats, fused = fresh()
+        try:
+            if fuse:
+                fused.fuse_into_backward(True)
+            for _ in range(2):
+                out = Rm._ProjectSH.apply(splats["means"], splats["quats"], splats["scales"], splats["opacities"],
+                                          splats["sh0"], splats["shN"], viewmats, K, campos, cfg)
+                _, means2d, _, conics, _, colors, opac_act, _, _ = out
+                r = rows.clone()     # (the views must share ONE base: the fast, copy-free hand-over)
+                torch.autograd.backward(
+                    [means2d, conics, colors, opac_act],
+                    [r[:, 0:2].view(1, N, 2), r[:, 2:5].view(1, N, 3), r[:, 6:9].view(1, N, 3), r[:, 5].view(1, N).reshape(N)])
+                if fuse:
+                    assert all(p.grad is None for p in splats.values())
+                fused.step()
+                fused.zero_grad(set_to_none=True)
+        finally:
+            Rm.set_backward_optimizer(None)
+        torch.cuda.synchronize()
+        st = {n: fused[n].state[splats[n]] for n in splats}
+        return ({n: p.detach() for n, p in splats.items()}, {n: s["exp_avg"] for n, s in st.items()},
+                {n: s["exp_avg_sq"] for n, s in st.items()}, {n: float(s["step"]) for n, s in st.items()})
+
+    try:
+        p0, m0, v0, s0 = run(False)
+        p1, m1, v1, s1 = run(True)
+    finally:
+        request_restore()
+    assert len(seen) == 4 and all(f for _, f in seen)     # every backward took the copy-free hand-over
+    from tests import parity_log
+    for n in p0:
+        assert s0[n] == s1[n] == 2.0, n
+        for what, a, b in (("param", p0[n], p1[n]), ("exp_avg", m0[n], m1[n]), ("exp_avg_sq", v0[n], v1[n])):
+            scale = float(a.abs().max())
+            err = (a - b).abs()
+            n_off = int((err > 1e-6 * scale + 1e-5 * a.abs()).sum())
+            parity_log.record("fused_adam_c4", tensor=n, what=what, elements=a.numel(), max_abs_err=float(err.max()),
+                              ref_max=scale, n_off=n_off)
+            # same gradient arithmetic, same adam_one: differences are fma contraction at most
+            assert n_off <= a.numel() // 100_000, (n, what, n_off, float(err.max()), scale)
+            assert float(err.max()) <= 1e-4 * scale, (n, what, float(err.max()), scale)
+    for n in ("means", "quats", "shN"):      # and the parameters did move
+        assert float((p1[n] - sc[n].cuda()).abs().max()) > 0, n

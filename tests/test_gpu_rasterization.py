@@ -150,6 +150,20 @@ def test_tiny_split_sh_layout(R):
     _check(*_run_both(R, sc, vm, K, W, H, split=True))
 
 
+@pytest.mark.parametrize("N,sh_degree", [(1001, 3), (1002, 3), (1003, 3), (1001, 2)])
+def test_multi_camera_rows_not_16_byte_aligned(R, N, sh_degree):
+    """Several cameras and N % 4 != 0: the projection forward's waves are formed over the flat
+    (camera, Gaussian) index, so for cameras >= 1 a wave's first shN row is 64 m - c N -- not a multiple
+    of 4 rows, i.e. its 11.5 KB block does not start on a 16-byte boundary and must NOT go through the
+    16-byte LDS-DMA slab prefetch of degree 3 (such waves take the band-wise dword reads).
+    Every earlier multi-camera test had N % 4 == 0. Both SH layouts, against the oracle."""
+    sc = scenes.make_scene(N, 9, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 40, 77], width=W, height=H, f=90.0, dist=2.5)
+    for split in (True, False):
+        _check(*_run_both(R, sc, vm, K, W, H, sh_degree=sh_degree, split=split))
+
+
 def test_tiny_rgb_ed_with_background(R):
     sc, vm, K, W, H = _tiny()
     bg = torch.tensor([[0.2, 0.5, 0.9]])
