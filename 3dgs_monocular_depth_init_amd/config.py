@@ -42,13 +42,61 @@ class MonocularDepthInitConfig:
 
 @dataclass
 class Config:
+    """The fields of the reference's Config (config.py:69-202) that the path and the training loop
+    around it read, with the reference's defaults, and `adjust_steps` (config.py:204-221)."""
     mdi: MonocularDepthInitConfig = field(default_factory=MonocularDepthInitConfig)
-    init_scale: float = 1.0
-    init_opa: float = 0.1
-    sh_degree: int = 3
-    near_plane: float = 0.01
-    far_plane: float = 1e10
-    packed: bool = False
-    antialiased: bool = False
-    batch_size: int = 1
-    ssim_lambda: float = 0.2
+    batch_size: int = 1                    # config.py:103
+    steps_scaler: float = 1.0              # :105
+    max_steps: int = 30_000                # :108
+    eval_steps: list = field(default_factory=lambda: [7_000, 30_000])    # :110
+    save_steps: list = field(default_factory=lambda: [7_000, 30_000])    # :112
+    save_final_ply: bool = True            # :113
+    init_type: str = "sfm"                 # :116  sfm | random | monocular_depth
+    init_num_pts: int = 100_000            # :121
+    init_extent: float = 3.0               # :123
+    sh_degree: int = 3                     # :125
+    sh_degree_interval: int = 1000         # :127
+    init_opa: float = 0.1                  # :129
+    init_scale: float = 1.0                # :131
+    ssim_lambda: float = 0.2               # :133
+    near_plane: float = 0.01               # :136
+    far_plane: float = 1e10                # :138
+    strategy: object = None                # :141-143 DefaultStrategy | MCMCStrategy (None -> DefaultStrategy())
+    packed: bool = False                   # :145
+    sparse_grad: bool = False              # :147
+    antialiased: bool = False              # :149
+    random_background: bool = False        # :152
+    opacity_reg: float = 0.0               # :155
+    scale_reg: float = 0.0                 # :157
+    depth_loss: bool = False               # :183
+    depth_lambda: float = 1e-2             # :185
+    absgrad: bool = False                  # (strategy.absgrad, runner.py:352-356)
+    camera_model: str = "pinhole"          # :97
+    # not in the reference: list a (tile, Gaussian) pair only when its alpha >= 1/255 ellipse reaches the
+    # tile -- same image and gradients (runner.RasterConfig.tight_tiles)
+    tight_tiles: bool = True
+
+    def __post_init__(self):
+        if self.strategy is None:
+            from .strategy import DefaultStrategy
+            self.strategy = DefaultStrategy()
+
+    def adjust_steps(self, factor: float):
+        """config.py:204-221, verbatim semantics (int() truncation, which fields scale)."""
+        from .strategy import DefaultStrategy, MCMCStrategy
+        self.eval_steps = [int(i * factor) for i in self.eval_steps]
+        self.save_steps = [int(i * factor) for i in self.save_steps]
+        self.max_steps = int(self.max_steps * factor)
+        self.sh_degree_interval = int(self.sh_degree_interval * factor)
+        strategy = self.strategy
+        if isinstance(strategy, DefaultStrategy):
+            strategy.refine_start_iter = int(strategy.refine_start_iter * factor)
+            strategy.refine_stop_iter = int(strategy.refine_stop_iter * factor)
+            strategy.reset_every = int(strategy.reset_every * factor)
+            strategy.refine_every = int(strategy.refine_every * factor)
+        elif isinstance(strategy, MCMCStrategy):
+            strategy.refine_start_iter = int(strategy.refine_start_iter * factor)
+            strategy.refine_stop_iter = int(strategy.refine_stop_iter * factor)
+            strategy.refine_every = int(strategy.refine_every * factor)
+        else:
+            raise TypeError(f"unknown strategy {type(strategy).__name__}")

@@ -100,6 +100,7 @@ class RasterConfig:
     antialiased: bool = False
     absgrad: bool = False
     camera_model: str = "pinhole"
+    sh_degree_interval: int = 1000      # config.py:127 (scaled by Config.adjust_steps)
     # list a (tile, Gaussian) pair only when the ellipse alpha >= 1/255 reaches the tile (exact
     # test) instead of gsplat's bounding-rectangle rule: same image and gradients, ~17 % fewer
     # pairs on the c4 scene (rendering.rasterization `_tight_tiles`)
@@ -153,17 +154,32 @@ def train_step(
     strategy_state=None,
     opacity_reg: float = 0.0,   # runner.py:535-539 (0.01 in the "mcmc" preset, trainer.py:83-92)
     scale_reg: float = 0.0,     # runner.py:540-545
+    random_background: bool = False,    # runner.py:493-495 (config.py:152)
+    masks: Optional[Tensor] = None,     # runner.py:449, 363
+    depth_points: Optional[Tensor] = None,   # runner.py:450-452, 511-529 (cfg.depth_loss): [C,M,2] pixel coordinates
+    depth_gt: Optional[Tensor] = None,       # [C,M]
+    depth_lambda: float = 1e-2,
+    scene_scale: float = 1.0,
+    before_update=None,         # callable(loss, info): runs after backward, before strategy / optimizer
+                                # (the reference's checkpoint point, runner.py:592-637); suspends the fusion
 ) -> Tuple[Tensor, Dict]:
-    """One iteration of Runner.train's body (runner.py:464-547, 676-689):
+    """One iteration of Runner.train's body (runner.py:464-547, 639-689):
     SH-degree schedule, render, L1 (+ optional SSIM term), backward,
-    optional gradient synchronisation, Adam step, zero_grad."""
+    optional gradient synchronisation, strategy, Adam step, zero_grad."""
     height, width = pixels.shape[1:3]
-    sh_degree_to_use = min(step // 1000, cfg.sh_degree)                 # runner.py:464
+    sh_degree_to_use = min(step // max(cfg.sh_degree_interval, 1), cfg.sh_degree)   # runner.py:464
+    depth_loss = depth_points is not None
     renders, alphas, info = rasterize_splats(
-        splats, camtoworlds, Ks, width, height, cfg,
+        splats, camtoworlds, Ks, width, height, cfg, masks=masks,
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
-        render_mode="RGB")
-    colors = renders if renders.shape[-1] == 3 else renders[..., :3]     # (no slice node in the RGB case)
+        render_mode="RGB+ED" if depth_loss else "RGB")                   # runner.py:476
+    if renders.shape[-1] == 4:                                           # runner.py:479-482
+        colors, depths = renders[..., 0:3], renders[..., 3:4]
+    else:
+        colors, depths = renders, None                                   # (no slice node in the RGB case)
+    if random_background:                                                # runner.py:493-495
+        background = torch.rand(1, 3, device=colors.device)
+        colors = colors + background * (1.0 - alphas)
     if strategy is not None:
         strategy.step_pre_backward(splats, optimizers, strategy_state, step, info)   # runner.py:497
     if ssim_lambda > 0.0:
@@ -172,6 +188,14 @@ def train_step(
     else:
         from .losses import l1_loss
         loss = l1_loss(colors, pixels)                                  # runner.py:506
+    if depth_loss:                                                       # runner.py:511-529
+        import torch.nn.functional as F
+        pts = torch.stack([depth_points[:, :, 0] / (width - 1) * 2 - 1,
+                           depth_points[:, :, 1] / (height - 1) * 2 - 1], dim=-1)    # normalize to [-1, 1]
+        d = F.grid_sample(depths.permute(0, 3, 1, 2), pts.unsqueeze(2), align_corners=True)   # [C,1,M,1]
+        d = d.squeeze(3).squeeze(1)
+        disp = torch.where(d > 0.0, 1.0 / d, torch.zeros_like(d))       # loss in disparity space
+        loss = loss + F.l1_loss(disp, 1.0 / depth_gt) * scene_scale * depth_lambda
     if opacity_reg > 0.0:                                                # runner.py:535-539
         loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
     if scale_reg > 0.0:                                                  # runner.py:540-545
@@ -181,7 +205,8 @@ def train_step(
     fused = _R._BACKWARD_OPTIMIZER
     # reference order on the steps where the strategy edits parameters: backward -> strategy ->
     # optimizer (runner.py:638-679); the fused update would land before the strategy
-    ordered = fused is not None and strategy is not None and strategy.mutates_params(step)
+    ordered = fused is not None and ((strategy is not None and strategy.mutates_params(step))
+                                     or before_update is not None)
     if fused is not None and not ordered and (opacity_reg > 0.0 or scale_reg > 0.0):
         # (on `ordered` steps -- every step of MCMCStrategy, whose preset uses both regularisers --
         # the fusion is suspended: the regularisers' gradients accumulate into .grad next to the
@@ -201,6 +226,8 @@ def train_step(
             _R.set_backward_optimizer(fused)
     if grad_sync is not None:
         grad_sync()
+    if before_update is not None:
+        before_update(loss.detach(), info)
     if strategy is not None:                                             # runner.py:639-658
         from .strategy import MCMCStrategy
         if isinstance(strategy, MCMCStrategy):
@@ -233,3 +260,209 @@ def train_step(
     if grad_sync is not None and hasattr(grad_sync, "finish"):
         grad_sync.finish()           # chunks no optimizer consumed (e.g. optimizers=None)
     return loss.detach(), info
+
+
+def raster_config_of(cfg) -> RasterConfig:
+    """The RasterConfig a reference-style Config (config.Config) implies."""
+    return RasterConfig(
+        sh_degree=cfg.sh_degree, near_plane=cfg.near_plane, far_plane=cfg.far_plane, packed=cfg.packed,
+        sparse_grad=cfg.sparse_grad, antialiased=cfg.antialiased,
+        absgrad=bool(getattr(cfg.strategy, "absgrad", False) or getattr(cfg, "absgrad", False)),   # runner.py:352-356
+        camera_model=cfg.camera_model, sh_degree_interval=cfg.sh_degree_interval,
+        tight_tiles=getattr(cfg, "tight_tiles", True))
+
+
+@torch.no_grad()
+def evaluate(splats, valset, cfg, device: str = "cuda") -> Dict[str, float]:
+    """Runner.eval (runner.py:711-789) without the image dumps, tensorboard and LPIPS (a downloaded
+    network): per held-out view render at the full SH degree, clamp to [0,1], PSNR (data range 1) and
+    mean SSIM (the 11x11 Gaussian-window kernel of losses.fused_ssim), averaged over the views;
+    `ellipse_time` = seconds per image bracketed by synchronisations as in runner.py:731-744."""
+    import time
+
+    from .losses import fused_ssim
+    rc = raster_config_of(cfg)
+    psnr, ssim, t = [], [], 0.0
+    for data in valset:
+        c2w = data["camtoworld"].to(device).reshape(1, 4, 4)
+        K = data["K"].to(device).reshape(1, 3, 3)
+        pixels = data["image"].to(device).float().reshape(1, *data["image"].shape[-3:]) / 255.0
+        masks = data["mask"].to(device)[None] if "mask" in data else None
+        height, width = pixels.shape[1:3]
+        torch.cuda.synchronize()
+        tic = time.time()
+        colors, _, _ = rasterize_splats(splats, c2w, K, width, height, rc, masks=masks, sh_degree=cfg.sh_degree,
+                                        near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+        torch.cuda.synchronize()
+        t += time.time() - tic
+        colors = torch.clamp(colors, 0.0, 1.0)
+        mse = torch.mean((colors - pixels) ** 2)
+        psnr.append(-10.0 * torch.log10(mse.clamp_min(1e-20)))
+        ssim.append(fused_ssim(colors.permute(0, 3, 1, 2), pixels.permute(0, 3, 1, 2), padding="same", train=False))
+    n = max(len(psnr), 1)
+    return {"psnr": float(torch.stack(psnr).mean()) if psnr else float("nan"),
+            "ssim": float(torch.stack(ssim).mean()) if ssim else float("nan"),
+            "ellipse_time": t / n, "num_GS": len(splats["means"])}
+
+
+def train(
+    splats,
+    optimizers: Dict[str, torch.optim.Optimizer],
+    trainset,                       # sequence of dicts as datasets/colmap.py:381-412 yields them:
+                                    # "camtoworld" [4,4], "K" [3,3], "image" [H,W,3] 0-255 (+ "mask", "points", "depths")
+    cfg,                            # config.Config (reference field names and defaults)
+    strategy_state=None,
+    *,
+    valset=None,
+    scene_scale: float = 1.0,
+    result_dir=None,                # checkpoints / stats are written only when given (rank 0 writes stats)
+    world_rank: int = 0,
+    world_size: int = 1,
+    grad_sync=None,                 # distributed.GradSync / GatherRowsSync for view-parallel replicas
+    fuse_optimizer: bool = True,    # wrap the six Adams in optim.FusedAdam, update inside the backward where legal
+    device: str = "cuda",
+    seed: int = 42,
+    progress=None,                  # callable(step, stats_dict) every `progress_every` steps (stands in for tqdm / tensorboard)
+    progress_every: int = 100,
+) -> Dict:
+    """Runner.train (runner.py:367-709) around `train_step`, with the reference's schedule:
+
+    * `ExponentialLR(optimizers["means"], gamma = 0.01 ** (1 / max_steps))`, stepped once per iteration
+      after the optimizers (runner.py:381-386, 687-689);
+    * SH degree `min(step // cfg.sh_degree_interval, cfg.sh_degree)` from step 0 (runner.py:464);
+    * loss `(1 - ssim_lambda) * L1 + ssim_lambda * (1 - SSIM)` (runner.py:506-510), optional depth loss,
+      opacity / scale regularisers, random background;
+    * `cfg.strategy` pre / post backward in the reference's order (runner.py:497-503, 639-658);
+    * the checkpoint `{"step", "splats"}` (+ PLY) at `step in [i - 1 for i in cfg.save_steps]` or the last
+      step, written BEFORE that step's update (runner.py:592-637), and `evaluate` at `cfg.eval_steps`
+      (runner.py:692-694);
+    * shuffled epochs over `trainset` in batches of `cfg.batch_size` (runner.py:411-441): the permutation
+      comes from a generator seeded with `seed` on every rank, rank r takes batch entries r, r + W, ...
+      (view-parallel replicas; the reference's Gaussian-sharded ranks each draw their own).
+
+    Out of scope, as in SURVEY.md section 2: viewer, tensorboard, pose / appearance optimisation, bilateral
+    grid, compression. Returns the run's statistics (per-interval ms/step, Gaussian counts, losses, the
+    learning rate at the end, evaluation results, checkpoint paths)."""
+    import json
+    import time
+    import warnings
+    from pathlib import Path
+
+    from . import io as gs_io
+    from . import rendering as _R
+    from .optim import FusedAdam, FusedSparseAdam
+    from .strategy import DefaultStrategy, MCMCStrategy
+
+    max_steps = int(cfg.max_steps)
+    strategy = cfg.strategy
+    rc = raster_config_of(cfg)
+    if strategy_state is None and strategy is not None:
+        strategy.check_sanity(splats, optimizers)                                    # runner.py:208
+        strategy_state = (strategy.initialize_state(scene_scale=scene_scale)         # runner.py:210-217
+                          if isinstance(strategy, DefaultStrategy) else strategy.initialize_state())
+    opt = optimizers
+    regs = cfg.opacity_reg > 0.0 or cfg.scale_reg > 0.0
+    fused_here = False
+    if fuse_optimizer and isinstance(optimizers, dict):
+        if cfg.sparse_grad:
+            opt = FusedSparseAdam(optimizers)
+        else:
+            opt = FusedAdam(optimizers)
+            if grad_sync is not None and hasattr(grad_sync, "attach"):
+                grad_sync.attach(opt)
+            elif grad_sync is None and world_size == 1 and not regs and _R._BACKWARD_OPTIMIZER is None:
+                opt.fuse_into_backward(True)
+                fused_here = True
+    means_opt = opt["means"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # (the fused launch never calls torch's Optimizer.step(), which is all the scheduler's
+        # "lr_scheduler.step() before optimizer.step()" warning looks at)
+        schedulers = [torch.optim.lr_scheduler.ExponentialLR(means_opt, gamma=0.01 ** (1.0 / max_steps))]
+    means_opt._opt_called = True
+    out_dir = Path(result_dir) if result_dir is not None else None
+    if out_dir is not None:
+        (out_dir / "ckpts").mkdir(parents=True, exist_ok=True)
+        (out_dir / "stats").mkdir(parents=True, exist_ok=True)
+    n_train = len(trainset)
+    gen = torch.Generator().manual_seed(seed)
+    B, W = int(cfg.batch_size), int(world_size)
+    order: list = []
+
+    def next_batch():
+        nonlocal order
+        need = B * W
+        if len(order) < need:                       # DataLoader(shuffle=True): a fresh permutation per epoch
+            order = order + torch.randperm(n_train, generator=gen).tolist()
+        take, order = order[:need], order[need:]
+        return [trainset[i] for i in take[world_rank::W]]
+
+    save_at = {i - 1 for i in cfg.save_steps} | {max_steps - 1}
+    eval_at = {i - 1 for i in cfg.eval_steps}
+    stats = {"steps": max_steps, "intervals": [], "evals": [], "checkpoints": [], "sh_degree_switches": [],
+             "refine_steps": 0, "reset_steps": 0}
+    last_deg = -1
+    global_tic = time.time()
+    torch.cuda.synchronize()
+    tic, tic_step = time.perf_counter(), 0
+    try:
+        for step in range(max_steps):
+            data = next_batch()
+            c2w = torch.stack([d["camtoworld"].to(device) for d in data])
+            Ks = torch.stack([d["K"].to(device) for d in data])
+            pixels = torch.stack([d["image"].to(device) for d in data]).float() / 255.0
+            masks = torch.stack([d["mask"].to(device) for d in data]) if "mask" in data[0] else None
+            extra = {}
+            if cfg.depth_loss:                                                         # runner.py:450-452
+                extra = dict(depth_points=torch.stack([d["points"].to(device) for d in data]),
+                             depth_gt=torch.stack([d["depths"].to(device) for d in data]),
+                             depth_lambda=cfg.depth_lambda, scene_scale=scene_scale)
+            deg = min(step // max(cfg.sh_degree_interval, 1), cfg.sh_degree)
+            if deg != last_deg:
+                stats["sh_degree_switches"].append((step, deg))
+                last_deg = deg
+            hook = None
+            if step in save_at and out_dir is not None:
+                def hook(loss, info, step=step):                                       # runner.py:592-637
+                    mem = torch.cuda.max_memory_allocated() / 1024 ** 3
+                    st = {"mem": mem, "ellipse_time": time.time() - global_tic, "num_GS": len(splats["means"])}
+                    (out_dir / "stats" / f"train_step{step:04d}_rank{world_rank}.json").write_text(json.dumps(st))
+                    path = gs_io.save_checkpoint(splats, step, out_dir / "ckpts", world_rank)
+                    stats["checkpoints"].append(str(path))
+                    if cfg.save_final_ply:
+                        gs_io.export_ply(splats, out_dir / "ckpts" / f"splats_{step}.ply")
+            if isinstance(strategy, DefaultStrategy) and strategy.mutates_params(step):
+                stats["reset_steps" if (step % strategy.reset_every == 0 and step > 0) else "refine_steps"] += 1
+            loss, info = train_step(
+                splats, opt, c2w, Ks, pixels, step, rc, ssim_lambda=cfg.ssim_lambda, grad_sync=grad_sync,
+                strategy=strategy, strategy_state=strategy_state, opacity_reg=cfg.opacity_reg,
+                scale_reg=cfg.scale_reg, random_background=cfg.random_background, masks=masks,
+                before_update=hook, **extra)
+            for sch in schedulers:                                                     # runner.py:687-689
+                sch.step()
+            if step in eval_at and valset is not None:                                 # runner.py:692-694
+                ev = evaluate(splats, valset, cfg, device)
+                ev["step"] = step
+                stats["evals"].append(ev)
+                if out_dir is not None and world_rank == 0:
+                    (out_dir / "stats" / f"val_step{step:04d}.json").write_text(json.dumps(ev))
+            if (step + 1) % progress_every == 0 or step == max_steps - 1:
+                lv = float(loss)                     # (the one host read per interval; also drains the queue)
+                now = time.perf_counter()
+                rec = {"step": step, "loss": lv, "num_GS": len(splats["means"]), "sh_degree": deg,
+                       "ms_per_step": (now - tic) / max(step + 1 - tic_step, 1) * 1e3,
+                       "lr_means": means_opt.param_groups[0]["lr"]}
+                stats["intervals"].append(rec)
+                tic, tic_step = now, step + 1
+                if progress is not None:
+                    progress(step, rec)
+    finally:
+        if fused_here:
+            _R.set_backward_optimizer(None)
+    torch.cuda.synchronize()
+    stats["seconds"] = time.time() - global_tic
+    stats["final_lr_means"] = means_opt.param_groups[0]["lr"]
+    stats["num_GS"] = len(splats["means"])
+    stats["peak_mem_gib"] = torch.cuda.max_memory_allocated() / 1024 ** 3
+    stats["strategy_state"] = None
+    return stats

@@ -37,32 +37,55 @@ for d in glob.glob(f"gpurun_out/{tag}_pmc_*/"):
                 pmc.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
 json.dump(pmc, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
 traffic = {}
-names = {"raster_bwd_kernel": "gsr_rasterize_bwd", "raster_fwd_kernel": "gsr_rasterize_fwd",
-         "project_fwd_kernel": "gsr_project_fwd", "project_bwd_kernel": "gsr_project_bwd",
-         "isect_emit_kernel": "gsr_isect_emit", "tile_sort_small_kernel": "gsr_tile_sort",
-         "adam_kernel": "gsr_adam_step"}
+# keyed on the FULL templated kernel name: project_bwd_kernel<true> (Adam fused in: the headline step's kernel)
+# and <false> (gradients written) are different kernels with different traffic; first match wins
+names = [("raster_bwd_kernel", "gsr_rasterize_bwd"), ("raster_fwd_kernel", "gsr_rasterize_fwd"),
+         ("project_fwd_kernel", "gsr_project_fwd"), ("project_bwd_kernel<true>", "gsr_project_bwd_adam"),
+         ("project_bwd_kernel<false>", "gsr_project_bwd"), ("bucket_count_kernel", "gsr_bucket_count"),
+         ("bucket_emit_kernel", "gsr_bucket_emit"), ("bucket_sort_kernel", "gsr_bucket_sort"),
+         ("tile_order_kernel", "gsr_tile_order"), ("l1_fwd_kernel", "gsr_l1_fwd"),
+         ("ssim_fwd_kernel", "gsr_ssim_fwd"), ("ssim_bwd_kernel", "gsr_ssim_bwd"),
+         ("isect_emit_kernel", "gsr_isect_emit"), ("tile_sort_small_kernel", "gsr_tile_sort"),
+         ("adam_kernel", "gsr_adam_step")]
+
+
+def entry_for(kernel_name):
+    for frag, entry in names:
+        if frag in kernel_name:
+            return entry
+    return None
+
+
 for k, cs in pmc.items():
-    for frag, entry in names.items():
-        if frag in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            traffic[entry] = int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
+    entry = entry_for(k)
+    if entry and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        traffic[entry] = int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
 valu = {}
 for k, cs in pmc.items():
-    for frag, entry in names.items():
-        if frag in k and "SQ_INSTS_VALU" in cs:
-            valu[entry] = int(cs["SQ_INSTS_VALU"])
+    entry = entry_for(k)
+    if entry and "SQ_INSTS_VALU" in cs:
+        valu[entry] = int(cs["SQ_INSTS_VALU"])
 # one file bench.py reads, with provenance: which digest, taken at which commit
 import subprocess
 try:
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     commit = None
-dominant = {"source": f"profiles/{tag}_pmc.json", "commit": commit, "kernels": {}}
+import hashlib
+from pathlib import Path
+csrc = Path(__file__).resolve().parents[1] / "3dgs_monocular_depth_init_amd" / "csrc"
+hashes = {f.name: hashlib.sha256(f.read_bytes()).hexdigest()[:16]
+          for f in sorted(csrc.glob("*")) if f.suffix in (".hip", ".h")}
+# (source_hashes: the csrc files as they were when the counters were digested -- run the digest at the tree the
+# profile was taken from; bench.py marks the counters stale when the compositing sources have changed since)
+dominant = {"source": f"profiles/{tag}_pmc.json", "commit": commit, "source_hashes": hashes, "kernels": {}}
 for k, cs in pmc.items():
-    for frag, entry in names.items():
-        if frag in k:
-            dominant["kernels"][entry] = {c: cs[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE",
-                                                           "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
-                                                           "SQ_BUSY_CYCLES") if c in cs}
+    entry = entry_for(k)
+    if entry:
+        dominant["kernels"][entry] = dict({c: cs[c] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE",
+                                                            "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+                                                            "SQ_BUSY_CYCLES", "TCC_HIT_sum", "TCC_MISS_sum",
+                                                            "TCC_EA0_ATOMIC_sum") if c in cs}, kernel=k)
 if dominant["kernels"]:
     json.dump(dominant, open("profiles/pmc_dominant.json", "w"), indent=1, sort_keys=True)
 if traffic:        # a digest of a counter set without FETCH/WRITE must not wipe the file
