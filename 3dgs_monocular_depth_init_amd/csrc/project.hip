@@ -501,6 +501,215 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
   }
 }
 
+
+// Optimizer in backward for ONE camera -- the training step's launch (runner.train_step, bench.py) -- over
+// whole waves of 64 Gaussians (the host sends a last partial wave to the generic kernel above).
+// Against project_bwd_kernel<true>, whose wave lived through seven dependent memory round trips
+// (profiles/r04a_pmc.json: 124 k cycles per wave, 70 % of them parked in s_waitcnt, VALU 15 % busy):
+//   * the wave's 64 shN rows (one contiguous 11.5 KB block) are requested FIRST, by LDS-DMA: they travel
+//     while the parameters and the gradient row are loaded and the projection is differentiated, and take
+//     no registers (the generic kernel staged them through 48 VGPRs);
+//   * the 64-byte gradient row is read as two 16-byte loads + one dword instead of nine dwords, each of
+//     which touched 64 different lines (9 M of the generic kernel's 28 M L2 requests per launch);
+//   * the SH gradients never live in registers: with one camera there is nothing to accumulate, so
+//     pass 2 overwrites each coefficient in the slab with its gradient right after reading it (the
+//     generic kernel carries v_coef[16][3] = 48 VGPRs through the whole kernel for the camera sum);
+//   * the registers that frees hold the Adam moments of the 14 short-row parameters, requested BEFORE the
+//     SH passes so that they arrive under ~400 VALU instructions, and the parameters themselves are
+//     reused from the loads at the top instead of being read again.
+#ifndef GSR_PBWD1_WAVES
+#define GSR_PBWD1_WAVES 4   // waves per workgroup of the single-camera kernel (no workgroup-level synchronisation in it)
+#endif
+__global__ void __launch_bounds__(64 * GSR_PBWD1_WAVES)
+project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *__restrict__ K,
+                         const float *__restrict__ campos, int width, int height, float eps2d,
+                         int sh_degree, const int32_t *__restrict__ radii,
+                         const float *__restrict__ grad_rows, const float *__restrict__ v_depths,
+                         const float *__restrict__ v_comps, int depth_channel,
+                         const float *__restrict__ opacities_act, AdamFused af) {
+  __shared__ __attribute__((aligned(16))) float sT[GSR_PBWD1_WAVES * 64 * 45];   // per-wave slabs: shN rows, then their gradients
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;                    // N is a multiple of 64: whole waves leave
+  const int lane = threadIdx.x & 63;
+  float *slab = &sT[(threadIdx.x >> 6) * (64 * 45)];
+  float *const P_shN = af.p[AF_SHN];
+  {
+    const float *src = P_shN + (int64_t)(i - lane) * 45;
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int idx = it * 64 + lane;
+      if (idx < 64 * 45 / 4) dma_16B(src + 4 * idx, slab + 256 * it);
+    }
+  }
+  // the short rows: parameters (kept for their own Adam update below), gradient row, visibility
+  const float *pm = af.p[AF_MEANS] + (int64_t)i * 3, *pq = af.p[AF_QUATS] + (int64_t)i * 4,
+              *ps = af.p[AF_SCALES] + (int64_t)i * 3, *p0 = af.p[AF_SH0] + (int64_t)i * 3;
+  float mean[3] = {pm[0], pm[1], pm[2]};
+  float q[4] = {pq[0], pq[1], pq[2], pq[3]};
+  const float s_raw[3] = {ps[0], ps[1], ps[2]};
+  const float c0[3] = {p0[0], p0[1], p0[2]};
+  const float o_raw = af.p[AF_OPAC][i];
+  const float4 r0 = *reinterpret_cast<const float4 *>(grad_rows + (int64_t)i * GSR_GRAD_ROW);
+  const float4 r1 = *reinterpret_cast<const float4 *>(grad_rows + (int64_t)i * GSR_GRAD_ROW + 4);
+  const float r8 = grad_rows[(int64_t)i * GSR_GRAD_ROW + 8];
+  const int2 rad = *reinterpret_cast<const int2 *>(radii + (int64_t)i * 2);
+  const float o_act = opacities_act[i];
+  const bool visible = rad.x > 0 && rad.y > 0;
+  float s[3] = {expf(s_raw[0]), expf(s_raw[1]), expf(s_raw[2])};
+  float v_mean[3] = {0.f, 0.f, 0.f}, v_q[4] = {0.f, 0.f, 0.f, 0.f}, v_s[3] = {0.f, 0.f, 0.f}, v_op = 0.f;
+  float v_c0[3] = {0.f, 0.f, 0.f};
+  float v_col[3] = {0.f, 0.f, 0.f};
+  float ux = 0.f, uy = 0.f, uz = 0.f, inv = 0.f;
+  if (visible) {
+    const gs::Mat3 covar = gs::quat_scale_to_covar(q, s);
+    gs::Mat3 v_covar = gs::mat3_zero();
+    float v_m2d[2] = {r0.x, r0.y};
+    float v_con[3] = {r0.z, r0.w, r1.x};
+    v_op = r1.y;
+    float v_depth = v_depths ? v_depths[i] : 0.f;
+    if (depth_channel >= 0) v_depth += grad_rows[(int64_t)i * GSR_GRAD_ROW + GSR_GR_COLOR + depth_channel];
+    const float v_comp = v_comps ? v_comps[i] : 0.f;
+    const gs::Camera cam = gs::load_camera(viewmat, K);
+    gs::project_ewa_vjp(cam, mean, covar, width, height, eps2d, v_m2d, v_depth, v_con, v_comp, v_mean, v_covar);
+    gs::quat_scale_to_covar_vjp(q, s, v_covar, v_q, v_s);
+    v_s[0] *= s[0];   // d exp(x) = exp(x)
+    v_s[1] *= s[1];
+    v_s[2] *= s[2];
+    v_col[0] = r1.z;
+    v_col[1] = r1.w;
+    v_col[2] = r8;
+    const float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
+    inv = 1.0f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-20f);
+    ux = dx * inv;
+    uy = dy * inv;
+    uz = dz * inv;
+  }
+  v_op *= o_act * (1.0f - o_act);   // sigmoid chain rule (0 for an invisible pair)
+  GSR_WAIT_VMEM();                   // the slab has arrived (everything above was needed anyway)
+  // Adam moments of the 14 short-row parameters: in flight during the SH passes
+  float m_s[14], v_m[14];
+  {
+    const int64_t o3 = (int64_t)i * 3, o4 = (int64_t)i * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      m_s[k] = af.m[AF_MEANS][o3 + k];
+      v_m[k] = af.v[AF_MEANS][o3 + k];
+      m_s[7 + k] = af.m[AF_SCALES][o3 + k];
+      v_m[7 + k] = af.v[AF_SCALES][o3 + k];
+      m_s[11 + k] = af.m[AF_SH0][o3 + k];
+      v_m[11 + k] = af.v[AF_SH0][o3 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m_s[3 + k] = af.m[AF_QUATS][o4 + k];
+      v_m[3 + k] = af.v[AF_QUATS][o4 + k];
+    }
+    m_s[10] = af.m[AF_OPAC][i];
+    v_m[10] = af.v[AF_OPAC][i];
+  }
+  float *cn = slab + lane * 45;      // this lane's row: coefficients in, gradients out
+  if (visible) {
+    // pass 1: pre-clamp colour, for the clamp_min(., 0) mask
+    float col[3] = {0.f, 0.f, 0.f};
+    gs::sh_visit(sh_degree, ux, uy, uz, [&](int k, float b, float, float, float) {
+      const float *ck = (k == 0) ? c0 : cn + (k - 1) * 3;
+      col[0] += b * ck[0];
+      col[1] += b * ck[1];
+      col[2] += b * ck[2];
+    });
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      if (col[ch] + 0.5f < 0.f) v_col[ch] = 0.f;
+    // pass 2: direction gradient; every coefficient is replaced by its gradient once it has been read
+    float vx = 0.f, vy = 0.f, vz = 0.f;
+    gs::sh_visit(sh_degree, ux, uy, uz, [&](int k, float b, float bx, float by, float bz) {
+      if (k == 0) {
+        const float dotc = c0[0] * v_col[0] + c0[1] * v_col[1] + c0[2] * v_col[2];
+        vx += bx * dotc;
+        vy += by * dotc;
+        vz += bz * dotc;
+        v_c0[0] = b * v_col[0];
+        v_c0[1] = b * v_col[1];
+        v_c0[2] = b * v_col[2];
+      } else {
+        float *ck = cn + (k - 1) * 3;
+        const float dotc = ck[0] * v_col[0] + ck[1] * v_col[1] + ck[2] * v_col[2];
+        vx += bx * dotc;
+        vy += by * dotc;
+        vz += bz * dotc;
+        ck[0] = b * v_col[0];
+        ck[1] = b * v_col[1];
+        ck[2] = b * v_col[2];
+      }
+    });
+    const float dot = vx * ux + vy * uy + vz * uz;   // through dir / |dir|
+    v_mean[0] += (vx - dot * ux) * inv;
+    v_mean[1] += (vy - dot * uy) * inv;
+    v_mean[2] += (vz - dot * uz) * inv;
+  }
+  {
+    // bands the active degree does not use (all of them for an invisible pair) have zero gradient
+    const int k_used = visible ? (sh_degree + 1) * (sh_degree + 1) : 1;
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+      if (k >= k_used) {
+        cn[(k - 1) * 3 + 0] = 0.f;
+        cn[(k - 1) * 3 + 1] = 0.f;
+        cn[(k - 1) * 3 + 2] = 0.f;
+      }
+  }
+  // Adam on the short rows: parameters from the registers loaded at the top, moments prefetched
+  {
+    auto upd = [&](int t, int64_t off, float pp, float g, int j) {
+      float mm = m_s[j], vv = v_m[j];
+      adam_one(pp, g, mm, vv, af.omb1, af.beta2, af.omb2, af.eps, af.step_size[t], af.bc2_sqrt[t]);
+      af.p[t][off] = pp;
+      af.m[t][off] = mm;
+      af.v[t][off] = vv;
+    };
+    const int64_t o3 = (int64_t)i * 3, o4 = (int64_t)i * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) upd(AF_MEANS, o3 + k, mean[k], v_mean[k], k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) upd(AF_QUATS, o4 + k, q[k], v_q[k], 3 + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) upd(AF_SCALES, o3 + k, s_raw[k], v_s[k], 7 + k);
+    upd(AF_OPAC, i, o_raw, v_op, 10);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) upd(AF_SH0, o3 + k, c0[k], v_c0[k], 11 + k);
+  }
+  // Adam on the wave's contiguous 64 x 45 block of shN / exp_avg / exp_avg_sq, coalesced 16-byte pieces,
+  // gradients from the slab (written row-wise above, read linearly here)
+  {
+    const int64_t base = (int64_t)(i - lane) * 45;
+    float4 *P4 = reinterpret_cast<float4 *>(P_shN + base);
+    float4 *M4 = reinterpret_cast<float4 *>(af.m[AF_SHN] + base);
+    float4 *V4 = reinterpret_cast<float4 *>(af.v[AF_SHN] + base);
+    const float4 *G4 = reinterpret_cast<const float4 *>(slab);
+    const float ss = af.step_size[AF_SHN], bc2 = af.bc2_sqrt[AF_SHN];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll GSR_ADAM_UNROLL
+    for (int it = 0; it < 12; ++it) {
+      const int idx = it * 64 + lane;
+      if (idx < 64 * 45 / 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v mmv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&M4[idx]));
+        const f4v vvv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&V4[idx]));
+        float4 pp = P4[idx], mm = make_float4(mmv.x, mmv.y, mmv.z, mmv.w), vv = make_float4(vvv.x, vvv.y, vvv.z, vvv.w);
+        const float4 gg = G4[idx];
+        adam_one(pp.x, gg.x, mm.x, vv.x, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+        adam_one(pp.y, gg.y, mm.y, vv.y, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+        adam_one(pp.z, gg.z, mm.z, vv.z, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+        adam_one(pp.w, gg.w, mm.w, vv.w, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+        P4[idx] = pp;
+        f4v mo = {mm.x, mm.y, mm.z, mm.w}, vo = {vv.x, vv.y, vv.z, vv.w};
+        __builtin_nontemporal_store(mo, reinterpret_cast<f4v *>(&M4[idx]));
+        __builtin_nontemporal_store(vo, reinterpret_cast<f4v *>(&V4[idx]));
+      }
+    }
+  }
+}
+
 }  // namespace gsr
 
 extern "C" int gsr_project_fwd(int C, int N, const float *means, const float *quats,
@@ -754,13 +963,41 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
   af.eps = (float)eps_d;
   af.omb1 = (float)(1.0 - beta1_d);
   af.omb2 = (float)(1.0 - beta2_d);
-  dim3 grid((unsigned)gsr::ceil_div(N, 256));
-  hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, N,
-                     af.p[gsr::AF_MEANS], af.p[gsr::AF_QUATS], af.p[gsr::AF_SCALES], viewmats, Ks,
-                     campos, width, height, eps2d, sh_degree, af.p[gsr::AF_SH0], 3,
-                     af.p[gsr::AF_SHN], 45, radii, grad_rows, grad_stride, v_depths, v_compensations,
-                     depth_channel, nullptr, nullptr, nullptr, nullptr, 3, nullptr, 45, 16,
-                     activations, opacities_act, nullptr, af);
-  GSR_CHECK_LAUNCH("project_bwd_adam");
+  // One camera, fp32 scratch rows, 16-byte aligned shN blocks: the whole waves go to the single-camera
+  // kernel, a last partial wave (N % 64 Gaussians) to the generic one.
+  int n_fast = 0;
+#ifndef GSR_PBWD_GENERIC_ONLY
+  if (C == 1 && grad_stride == GSR_GRAD_ROW && radii &&
+      ((((uintptr_t)af.p[gsr::AF_SHN]) | ((uintptr_t)af.m[gsr::AF_SHN]) | ((uintptr_t)af.v[gsr::AF_SHN]) |
+        ((uintptr_t)grad_rows)) & 15) == 0 && (((uintptr_t)radii) & 7) == 0)
+    n_fast = N & ~63;
+#endif
+  if (n_fast > 0) {
+    hipLaunchKernelGGL(gsr::project_bwd_adam1_kernel, dim3((unsigned)gsr::ceil_div(n_fast, 64 * GSR_PBWD1_WAVES)),
+                       dim3(64 * GSR_PBWD1_WAVES), 0,
+                       (hipStream_t)stream, n_fast, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii,
+                       grad_rows, v_depths, v_compensations, depth_channel, opacities_act, af);
+    GSR_CHECK_LAUNCH("project_bwd_adam (single camera)");
+  }
+  const int n_rest = N - n_fast;
+  if (n_rest > 0) {
+    const int64_t a0 = n_fast;
+    gsr::AdamFused at = af;
+    const int row_floats[gsr::AF_COUNT] = {3, 4, 3, 1, 3, 45};
+    for (int t = 0; t < gsr::AF_COUNT; ++t) {
+      at.p[t] += a0 * row_floats[t];
+      at.m[t] += a0 * row_floats[t];
+      at.v[t] += a0 * row_floats[t];
+    }
+    // (with n_fast > 0 this is C == 1: per-Gaussian arrays simply start a0 rows later)
+    hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, dim3((unsigned)gsr::ceil_div(n_rest, 256)), dim3(256), 0,
+                       (hipStream_t)stream, C, n_rest, at.p[gsr::AF_MEANS], at.p[gsr::AF_QUATS],
+                       at.p[gsr::AF_SCALES], viewmats, Ks, campos, width, height, eps2d, sh_degree,
+                       at.p[gsr::AF_SH0], 3, at.p[gsr::AF_SHN], 45, radii ? radii + a0 * 2 : nullptr,
+                       grad_rows + a0 * grad_stride, grad_stride, v_depths ? v_depths + a0 : nullptr,
+                       v_compensations ? v_compensations + a0 : nullptr, depth_channel, nullptr, nullptr,
+                       nullptr, nullptr, 3, nullptr, 45, 16, activations, opacities_act + a0, nullptr, at);
+    GSR_CHECK_LAUNCH("project_bwd_adam");
+  }
   return GSR_OK;
 }
