@@ -100,7 +100,40 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
 // in half AND packs two values into one register, so the work shrinks
 // 8 -> 4 -> 2 -> 1 registers. On return, every lane of (row r = lane/16,
 // half h = (lane/8)&1) holds the 64-lane total of v[TREE8_INDEX[h][r]].
-__device__ __forceinline__ float swap32_add(float a, float b) {
+#ifndef GSR_XLANE_LDS
+#define GSR_XLANE_LDS 0
+#endif
+#if GSR_XLANE_LDS
+// The two widest exchanges (across the 32-lane halves, across the 16-lane rows) through the LDS crossbar
+// (ds_bpermute_b32 / ds_swizzle_b32: no LDS memory is touched) instead of v_permlane32_swap /
+// v_permlane16_swap: a swap costs the VALU ~10 cycles (profiles/r02_valu_rate.jsonl), two v_cndmask + the
+// add 6, and the LDS pipe of the compositing backward is otherwise idle (profiles/r04a_pmc.json: 14 M LDS
+// against 237 M VALU instructions per launch). Same result layout as the swap versions.
+__device__ __forceinline__ float swap32_add(float a, float b, int lane) {
+  const bool hi = (lane & 32) != 0;
+  const float u = hi ? a : b;            // what the OTHER half adds up
+  const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, u)));
+  return (hi ? b : a) + t;
+}
+__device__ __forceinline__ float swap16_add(float p, float q, int lane) {
+  const bool odd = (lane & 16) != 0;
+  const float u = odd ? p : q;
+  // bitmask mode: and 0x1f, or 0, xor 0x10 -> lane ^ 16 inside each 32-lane half
+  const float t = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, u), 0x401f));
+  return (odd ? q : p) + t;
+}
+// all lanes end with the 64-lane total
+__device__ __forceinline__ float wave_sum_xlane(float v, int lane) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));
+  v = dpp_add<0xb1>(v);
+  v = dpp_add<0x4e>(v);
+  v = dpp_add<0x124>(v);
+  v = dpp_add<0x128>(v);
+  return v;
+}
+#else
+__device__ __forceinline__ float swap32_add(float a, float b, int) {
   // lanes 0-31: a folded over the two 32-lane halves; lanes 32-63: b folded
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   // NB: copy the elements out first -- `__builtin_bit_cast(float, r[1])` applied to
@@ -108,17 +141,19 @@ __device__ __forceinline__ float swap32_add(float a, float b) {
   const unsigned r0 = r[0], r1 = r[1];
   return __uint_as_float(r0) + __uint_as_float(r1);
 }
-__device__ __forceinline__ float swap16_add(float p, float q) {
+__device__ __forceinline__ float swap16_add(float p, float q, int) {
   // rows: [p0+p1, q0+q1, p2+p3, q2+q3]
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
   const unsigned r0 = r[0], r1 = r[1];
   return __uint_as_float(r0) + __uint_as_float(r1);
 }
+__device__ __forceinline__ float wave_sum_xlane(float v, int) { return wave_sum_lane63(v); }   // (lane 63 only)
+#endif
 __device__ __forceinline__ float tree_reduce8(const float v[8], int lane) {
-  const float s01 = swap32_add(v[0], v[1]), s23 = swap32_add(v[2], v[3]);
-  const float s45 = swap32_add(v[4], v[5]), s67 = swap32_add(v[6], v[7]);
-  const float r1 = swap16_add(s01, s23);     // rows: v0, v2, v1, v3 (16 partial lanes each)
-  const float r2 = swap16_add(s45, s67);     // rows: v4, v6, v5, v7
+  const float s01 = swap32_add(v[0], v[1], lane), s23 = swap32_add(v[2], v[3], lane);
+  const float s45 = swap32_add(v[4], v[5], lane), s67 = swap32_add(v[6], v[7], lane);
+  const float r1 = swap16_add(s01, s23, lane);     // rows: v0, v2, v1, v3 (16 partial lanes each)
+  const float r2 = swap16_add(s45, s67, lane);     // rows: v4, v6, v5, v7
   const float t1 = dpp_add<0x128>(r1);       // row_ror:8 -> fold the two 8-lane halves
   const float t2 = dpp_add<0x128>(r2);
   float u = (lane & 8) ? t2 : t1;

@@ -18,11 +18,21 @@
 
 #include "raster_common.h"
 
+#ifndef GSR_BWD_MASK_SWITCH
+#define GSR_BWD_MASK_SWITCH 0   // 1: fifteen straight-line bodies (one per quadrant mask) in the FAST batches
+#endif
 #ifndef GSR_BWD_WAVES
 #define GSR_BWD_WAVES 6   // waves per SIMD the CH <= 3 instantiation is register-allocated for
 #endif
 
 namespace gsr {
+
+#ifdef GSR_BWD_COUNT_EMPTY
+// Diagnostic build (tools/build_variants.sh count "-DGSR_BWD_COUNT_EMPTY=1"): [0] pairs composited, [1] pairs in
+// which NO pixel of the tile passed the alpha >= 1/255 test (their reduction and LDS row are all zeros),
+// [2] pairs composited in FAST batches. Read back with gsr_debug_bwd_counts.
+static __device__ unsigned long long g_bwd_counts[4] = {0, 0, 0, 0};
+#endif
 
 // Sum over the 16 lanes of each DPP row; every lane of a row ends with the row sum.
 __device__ __forceinline__ float row_sum16(float v) {
@@ -189,10 +199,15 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
     // One Gaussian against the tile. FAST (wave-uniform, decided per batch): every pixel
     // is active and no opacity of the batch exceeds the alpha clamp, so the tests against
     // last[] / qmax[] and the clamp handling are compiled out.
+#ifdef GSR_BWD_NO_FAST
+    const bool fast_batch = false;   // (experiment: one copy of the quadrant bodies instead of two)
+#else
     const bool fast_batch = (batch_end <= min_last) && !__any(can_clamp);
-    auto composite = [&](auto fast_tag, int j) {
+#endif
+    auto composite = [&](auto fast_tag, auto mask_tag, int j, unsigned qm_dyn) {
       constexpr bool FAST = decltype(fast_tag)::value;
-      unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT;
+      constexpr unsigned QMC = decltype(mask_tag)::value;   // 1..15: the pair's quadrant mask as a compile-time constant
+      unsigned qm = QMC ? QMC : qm_dyn;
       const int idx = batch_end - j;
       if (!FAST) {
 #pragma unroll
@@ -211,6 +226,9 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
       // conic in natural units for the gradient formulas: a = 2*ha/log2e etc.
       const float ca = Ac.z * (2.0f / LOG2E), cb = Ac.w * (1.0f / LOG2E), cc = Bc.x * (2.0f / LOG2E);
 
+#ifdef GSR_BWD_COUNT_EMPTY
+      bool any_valid = false;
+#endif
       float g_xy[2] = {0.f, 0.f}, g_con[3] = {0.f, 0.f, 0.f}, g_vs = 0.f, g_col[CH];
       float g_abs[2] = {0.f, 0.f};
 #pragma unroll
@@ -233,6 +251,9 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           // sigma's sign bit is OR-ed into ov, so one compare covers both
           bool valid = with_sign_of(ov, sg) >= gs::ALPHA_THRESHOLD;
           if (!FAST) valid = valid && (idx <= last[q]);
+#ifdef GSR_BWD_COUNT_EMPTY
+          any_valid |= valid;
+#endif
           const float ovv = valid ? ov : 0.f;
           // FAST: opacity <= 0.999 and exp2(-sigma) <= 1, so the clamp cannot bind
           const float a = FAST ? ovv : fminf(gs::ALPHA_MAX, ovv);
@@ -270,6 +291,16 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
         }
        }
       }
+#ifdef GSR_BWD_COUNT_EMPTY
+      {
+        const bool none = !__any(any_valid);
+        if (lane == 0) {
+          atomicAdd(&g_bwd_counts[0], 1ull);
+          if (none) atomicAdd(&g_bwd_counts[1], 1ull);
+          if (FAST) atomicAdd(&g_bwd_counts[2], 1ull);
+        }
+      }
+#endif
       // 8 of the sums go through the lane-swap halving tree (18 VALU for all 8), the
       // zeroth moment through a plain wave sum that ends in lane 63; the writer lanes
       // (wfield) store everything with one predicated ds_write into the 64-byte LDS row.
@@ -277,7 +308,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
         const float tv[8] = {g_xy[0], g_xy[1], g_con[0], g_con[1], g_con[2], g_col[0],
                              (CH > 1) ? g_col[1] : 0.f, (CH > 2) ? g_col[2] : 0.f};
         float u = tree_reduce8(tv, lane);
-        const float r_s = wave_sum_lane63(g_vs);
+        const float r_s = wave_sum_xlane(g_vs, lane);
         u = (lane == 63) ? r_s : u;
         u = (lane == 1) ? 1.0f : u;
         float *row = &sG[j][0];
@@ -300,9 +331,28 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
       }
     };
     if (fast_batch) {
-      for (int j = 0; j < n; ++j) composite(std::true_type{}, j);
+#if GSR_BWD_MASK_SWITCH
+      // one straight-line body per quadrant mask (FAST batches: the mask is exactly the pair word's): the
+      // per-quadrant scalar tests disappear and the bodies of a mask's quadrants can be scheduled together
+      for (int j = 0; j < n; ++j) {
+        const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT;
+        switch (qm) {
+#define GSR_CASE(M) case M: composite(std::true_type{}, std::integral_constant<unsigned, M>{}, j, qm); break;
+          GSR_CASE(1) GSR_CASE(2) GSR_CASE(3) GSR_CASE(4) GSR_CASE(5) GSR_CASE(6) GSR_CASE(7) GSR_CASE(8)
+          GSR_CASE(9) GSR_CASE(10) GSR_CASE(11) GSR_CASE(12) GSR_CASE(13) GSR_CASE(14) GSR_CASE(15)
+#undef GSR_CASE
+          default: break;
+        }
+      }
+#else
+      for (int j = 0; j < n; ++j)
+        composite(std::true_type{}, std::integral_constant<unsigned, 0>{}, j,
+                  (unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT);
+#endif
     } else {
-      for (int j = 0; j < n; ++j) composite(std::false_type{}, j);
+      for (int j = 0; j < n; ++j)
+        composite(std::false_type{}, std::integral_constant<unsigned, 0>{}, j,
+                  (unsigned)__builtin_amdgcn_readlane((int)pw, j) >> PAIR_MASK_SHIFT);
     }
     TL_MARK(2);        // (2) the compositing loop
     n_prev = n;
@@ -326,7 +376,7 @@ __global__ void debug_tree_reduce8_kernel(const float *__restrict__ in, float *_
   out[lane] = tree_reduce8(v, lane);
   idx_out[lane] = tree8_index(lane);
   out[64 + lane] = wave_sum(v[0]);
-  out[128 + lane] = wave_sum_lane63(v[1]);   // only lane 63 is meaningful
+  out[128 + lane] = wave_sum_xlane(v[1], lane);   // only lane 63 is meaningful
 }
 
 template <int CH>
@@ -394,6 +444,18 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
 #undef GSR_BWD_CASE
   return GSR_EINVAL;
 }
+
+#ifdef GSR_BWD_COUNT_EMPTY
+extern "C" int gsr_debug_bwd_counts(unsigned long long *out4, int reset) {
+  GSR_CHECK_HIP(hipDeviceSynchronize());
+  GSR_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(gsr::g_bwd_counts), 4 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_bwd_counts), z, sizeof(z)));
+  }
+  return GSR_OK;
+}
+#endif
 
 #ifdef GSR_RASTER_TIMELINE
 // buf: [n_tiles, 8] uint64 on the device (or NULL to switch off)
