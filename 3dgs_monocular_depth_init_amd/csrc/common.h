@@ -49,6 +49,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return (b & 7) * per + (b >> 3);
 }
 
+// Experiment knobs (A/B scaffolding: occupancy padding of the compositing kernels, GEMM core selection of the
+// depth network) are environment variables ONLY in builds made with -DGSR_EXPERIMENT_KNOBS=1
+// (tools/build_variants.sh knobs "-DGSR_EXPERIMENT_KNOBS=1"); the product library never calls getenv.
+#ifdef GSR_EXPERIMENT_KNOBS
+#include <stdlib.h>
+static inline int gsr_knob_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+static inline int gsr_knob_int(const char *, int dflt) { return dflt; }
+#endif
+
 #if defined(__HIPCC__)
 // ---- wave64 reductions on DPP (no LDS traffic) ------------------------------
 template <int CTRL, int ROW_MASK = 0xf>

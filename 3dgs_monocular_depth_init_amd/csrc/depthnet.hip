@@ -1320,7 +1320,7 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   // (only where the rounding matters, up to two rounds: 8192^3 is 1390 us wide, 1560 us narrow)
   // (N <= 64: one column tile either way, and the 64-wide one does half the MFMA work of the 128-wide --
   // Metric3D-small's 48-channel maps)
-  static const int wide_small = getenv("GSR_DN_GEMM_WIDE_SMALL_N") ? atoi(getenv("GSR_DN_GEMM_WIDE_SMALL_N")) : 0;   // bench knob
+  static const int wide_small = gsr::gsr_knob_int("GSR_DN_GEMM_WIDE_SMALL_N", 0);   // bench knob
   const bool narrow = (p.N <= 64 && !wide_small) ||
                       (p.N > 64 && b128 <= 1024 && 0.7 * gsr::ceil_div(b64, 768) < 1.0 * gsr::ceil_div(b128, 512));
   // The 256x256 eight-phase core wherever its grid occupies the chip: from 112 workgroups (one round on
@@ -1328,7 +1328,7 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   // 459 -> 679, 3349x4096x1024 495 -> 860, 40964x256x2304 582 -> 811, 40964x512x2880 666 -> 908,
   // 4096^3 943 -> 1279; with 56-106 workgroups (N = 1024 at 3349 rows, the 1/7 and 1/14 maps) the
   // 128-row tiles below stay ahead. GSR_DN_GEMM_CORE=1 / 4 forces a core (bench knob).
-  static const int force_core = getenv("GSR_DN_GEMM_CORE") ? atoi(getenv("GSR_DN_GEMM_CORE")) : 0;
+  static const int force_core = gsr::gsr_knob_int("GSR_DN_GEMM_CORE", 0);
   const int b256 = gsr::ceil_div(p.M, 256) * gsr::ceil_div(p.N, 256);
   // (gemm8p addresses its operands with 32-bit byte offsets)
   const bool fits32 = (int64_t)p.M * p.lda * 2 < (1ll << 32) && (int64_t)p.N * p.K * 2 < (1ll << 32);
@@ -1362,8 +1362,8 @@ static int launch_gemm(const GemmArgs &p, void *stream) {
   }
   // few 128x64 workgroups: 64x64 tiles (twice the workgroups, each walks half the rows): the 1/14-resolution
   // convolutions 33 -> 21 us each
-  static const int no_small = getenv("GSR_DN_GEMM_NO64") ? atoi(getenv("GSR_DN_GEMM_NO64")) : 0;   // bench knobs
-  static const int max64 = getenv("GSR_DN_GEMM_64_MAX") ? atoi(getenv("GSR_DN_GEMM_64_MAX")) : 450;
+  static const int no_small = gsr::gsr_knob_int("GSR_DN_GEMM_NO64", 0);   // bench knobs
+  static const int max64 = gsr::gsr_knob_int("GSR_DN_GEMM_64_MAX", 450);
   // (measured per shape, tools/depthnet_shapes.py: up to 450 workgroups of 128 x 64 the smaller tiles win or tie
   // -- 3349 x 1024 x 1024 31 -> 24 us, 13376 x 256 x 3456 59 -> 55 us -- except at K = 9216: 140 -> 148 us)
   // (and from 256 workgroups up only to K = 3584: 3349 x 1024 x 4096 takes 48.6 us on 128 x 64, 51.7 us on 64 x 64)

@@ -12,7 +12,6 @@
 // atomics per Gaussian. The flush of batch k runs at the top of batch k+1, BEFORE
 // the DMA of batch k+2 is issued: the batch-top wait (vmcnt(0), the DMA has no other
 // completion signal) then only ever waits for atomics that are a whole batch old.
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -386,8 +385,7 @@ static int launch_bwd(int n_tiles, const float *records, const float *background
                       const float *render_alphas, const int32_t *last_ids,
                       const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *grad_rows, hipStream_t stream) {
-  const char *pv = getenv("GSR_BWD_LDS_PAD");   // experiment knob: see raster_fwd.hip
-  const unsigned pad = pv ? (unsigned)atoi(pv) : 0u;
+  const unsigned pad = (unsigned)gsr_knob_int("GSR_BWD_LDS_PAD", 0);   // experiment knob: see raster_fwd.hip (0 in the product build)
   if (absgrad)
     hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), pad, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,

@@ -78,8 +78,14 @@ __device__ __forceinline__ PairConic make_pair_conic(float mx, float my, float a
   p.hc = 0.5f * c;
   p.sx = -b * ia;
   p.sy = -b * ic;
-  p.kx = 0.5f * (a - b * b * ic);
-  p.ky = 0.5f * (c - b * b * ia);
+  // kx = (a - b^2/c)/2 = det/(2c), ky = det/(2a) with det = a c - b^2 as a compensated difference of
+  // products (Kahan): for a needle-like rotated Gaussian (conic eigenvalues ~3 and ~1e-4) the plain
+  // a - b*b*rcp(c) cancels to ~1e-3 relative error, which times de^2 near the alpha = 1/255 boundary
+  // exceeded tau's safety margin -- a marginally visible pair or quadrant could be dropped.
+  const float w = b * b;
+  const float det = fmaf(a, c, -w) + fmaf(-b, b, w);
+  p.kx = 0.5f * det * ic;
+  p.ky = 0.5f * det * ia;
   p.tau_m = alpha_tau(op);
   p.clamp = op > gs::ALPHA_MAX;
   return p;

@@ -16,7 +16,6 @@
 // (profiles/r03_fwd_timeline_before.json). Also built and rejected in round 3: reading each record
 // with scalar loads into SGPRs instead of staging it (no LDS, 54 VGPRs): 0.198 ms against 0.145 ms,
 // every record is a scalar-cache miss (profiles/r03_ab_scalar_records.log).
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -197,13 +196,10 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   }
 }
 
-// Experiment knob (tools/ab_env.sh, profiles/r03_ab_occupancy.log): extra dynamic LDS per workgroup
-// lowers the number of resident waves without touching the code object: GSR_FWD_LDS_PAD /
-// GSR_BWD_LDS_PAD = bytes. Unset = 0.
-static unsigned occupancy_pad(const char *var) {
-  const char *v = getenv(var);
-  return v ? (unsigned)atoi(v) : 0u;
-}
+// Experiment knob (tools/ab_env.sh, profiles/r03_ab_occupancy.log; builds with -DGSR_EXPERIMENT_KNOBS only): extra
+// dynamic LDS per workgroup lowers the number of resident waves without touching the code object:
+// GSR_FWD_LDS_PAD / GSR_BWD_LDS_PAD = bytes. The product build has the constant 0 here.
+static unsigned occupancy_pad(const char *var) { return (unsigned)gsr_knob_int(var, 0); }
 
 template <int CH>
 static int launch_fwd(int n_tiles, const float *records, const float *backgrounds, int width,

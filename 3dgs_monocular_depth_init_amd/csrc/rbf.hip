@@ -17,14 +17,31 @@
 namespace gsr {
 namespace rbf {
 
-enum Kernel { K_LINEAR = 0, K_TPS = 1, K_CUBIC = 2 };
+// the scale-invariant kernels of scipy / torchrbf (the only ones usable without `epsilon`, which the
+// reference's call never passes): minimum polynomial degree 0, 1, 1, 2
+enum Kernel { K_LINEAR = 0, K_TPS = 1, K_CUBIC = 2, K_QUINTIC = 3, K_COUNT = 4 };
+constexpr int MAX_MONOMIALS = 6;
 
 __device__ __forceinline__ double phi(double r, int kernel) {
   if (kernel == K_LINEAR) return -r;
   if (kernel == K_CUBIC) return r * r * r;
+  if (kernel == K_QUINTIC) return -(r * r) * (r * r) * r;
   return r == 0.0 ? 0.0 : r * r * log(r);
 }
-__device__ __forceinline__ int n_monomials(int kernel) { return kernel == K_LINEAR ? 1 : 3; }
+__host__ __device__ __forceinline__ int n_monomials(int kernel) {
+  return kernel == K_LINEAR ? 1 : (kernel == K_QUINTIC ? 6 : 3);
+}
+// monomial m of the normalised point (u, v), scipy's order (_monomial_powers): 1, u, v, u^2, u v, v^2
+__device__ __forceinline__ double monomial(int m, double u, double v) {
+  switch (m) {
+    case 0: return 1.0;
+    case 1: return u;
+    case 2: return v;
+    case 3: return u * u;
+    case 4: return u * v;
+    default: return v * v;
+  }
+}
 
 // min / max of the sites -> shift, scale (scipy: (max + min) / 2, (max - min) / 2, 1 where that is 0)
 __global__ void __launch_bounds__(1024)
@@ -69,8 +86,7 @@ assemble_kernel(int P, int n, const float *__restrict__ y, const float *__restri
   const int i = (int)(idx / n), j = (int)(idx - (int64_t)i * n);
   double v = 0.0;
   auto mono = [&](int site, int m) -> double {
-    if (m == 0) return 1.0;
-    return ((double)y[2 * site + (m - 1)] - ss[m - 1]) / ss[2 + (m - 1)];
+    return monomial(m, ((double)y[2 * site] - ss[0]) / ss[2], ((double)y[2 * site + 1] - ss[1]) / ss[3]);
   };
   if (i < P && j < P) {
     const double dx = (double)y[2 * i] - (double)y[2 * j], dy = (double)y[2 * i + 1] - (double)y[2 * j + 1];
@@ -204,8 +220,11 @@ eval_grid_kernel(int P, const float *__restrict__ y, const double *__restrict__ 
     __syncthreads();
   }
   if (q >= qw * qh) return;
-  acc += coeffs[P];
-  if (n_monomials(kernel) == 3) acc += coeffs[P + 1] * ((x0 - ss[0]) / ss[2]) + coeffs[P + 2] * ((x1 - ss[1]) / ss[3]);
+  {
+    const double u = (x0 - ss[0]) / ss[2], v = (x1 - ss[1]) / ss[3];
+    const int R = n_monomials(kernel);
+    for (int m = 0; m < R; ++m) acc += coeffs[P + m] * monomial(m, u, v);
+  }
   out[q] = (float)acc;
 }
 
@@ -233,16 +252,16 @@ bilinear_ac_t_kernel(int qw, int qh, const float *__restrict__ src, int W, int H
 using namespace gsr::rbf;
 
 extern "C" int64_t gsr_rbf_workspace_bytes(int P) {
-  const int64_t n = (int64_t)P + 3;
+  const int64_t n = (int64_t)P + MAX_MONOMIALS;
   return (n * n + n + 8) * (int64_t)sizeof(double) + 256;
 }
 
 extern "C" int gsr_rbf_fit(int P, const float *sites_xy, const float *values, double smoothing, int kernel,
                            void *workspace, int64_t workspace_bytes, double *coeffs, double *shift_scale,
                            void *stream) {
-  GSR_REQUIRE(P >= 1 && kernel >= 0 && kernel <= 2 && smoothing >= 0.0, "rbf_fit: P=%d kernel=%d", P, kernel);
+  GSR_REQUIRE(P >= 1 && kernel >= 0 && kernel < K_COUNT && smoothing >= 0.0, "rbf_fit: P=%d kernel=%d", P, kernel);
   GSR_REQUIRE(sites_xy && values && workspace && coeffs && shift_scale, "rbf_fit: null pointer");
-  const int R = kernel == K_LINEAR ? 1 : 3;
+  const int R = n_monomials(kernel);
   GSR_REQUIRE(P >= R, "rbf_fit: %d sites cannot determine a polynomial of %d terms", P, R);
   const int n = P + R;
   GSR_REQUIRE(workspace_bytes >= gsr_rbf_workspace_bytes(P) && ((uintptr_t)workspace & 7) == 0, "rbf_fit: workspace");
@@ -273,7 +292,7 @@ extern "C" int gsr_rbf_fit(int P, const float *sites_xy, const float *values, do
 
 extern "C" int gsr_rbf_eval_grid(int P, const float *sites_xy, const double *coeffs, const double *shift_scale,
                                  int kernel, int qw, int qh, float *out, void *stream) {
-  GSR_REQUIRE(P >= 1 && kernel >= 0 && kernel <= 2 && qw >= 1 && qh >= 1, "rbf_eval_grid: bad sizes");
+  GSR_REQUIRE(P >= 1 && kernel >= 0 && kernel < K_COUNT && qw >= 1 && qh >= 1, "rbf_eval_grid: bad sizes");
   GSR_REQUIRE(sites_xy && coeffs && shift_scale && out, "rbf_eval_grid: null pointer");
   hipLaunchKernelGGL(eval_grid_kernel, dim3((unsigned)gsr::ceil_div(qw * qh, 256)), dim3(256), 0, (hipStream_t)stream,
                      P, sites_xy, coeffs, shift_scale, kernel, qw, qh, out);

@@ -447,7 +447,10 @@ extern "C" int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_a
 namespace gsr {
 // torch.optim.SparseAdam (the reference's optimizer under cfg.sparse_grad, runner.py:130, 661-679) on the
 // rows a step actually rendered: row r of every tensor is updated iff visible[r] != 0, every other row --
-// parameter AND moments -- is left alone. Arithmetic as torch/optim/_functional.py sparse_adam:
+// parameter AND moments -- is left alone. visible[r] = the NUMBER of cameras of the batch that render row r: the
+// reference builds sparse_coo_tensor(gaussian_ids, grad[gaussian_ids]) over the (camera, Gaussian) pairs, and
+// SparseAdam's coalesce() sums the duplicates, i.e. a row seen by k cameras steps on k times its dense gradient
+// (runner.py:661-672; with one camera k = 1). Arithmetic as torch/optim/_functional.py sparse_adam:
 //   m += (g - m) (1 - b1);  v += (g^2 - v) (1 - b2);  p -= step_size * m / (sqrt(v) + eps),
 //   step_size = lr sqrt(1 - b2^t) / (1 - b1^t)  (eps is NOT divided by the bias correction, unlike Adam).
 constexpr int SPARSE_ADAM_MAX_TENSORS = 8;
@@ -468,8 +471,9 @@ sparse_adam_kernel(SparseAdamArgs a, const uint8_t *__restrict__ visible) {
   int t = 0;
   while (i >= a.first[t + 1]) ++t;
   const int64_t e = i - a.first[t];
-  if (!visible[e / a.row_len[t]]) return;
-  const float g = a.g[t][e];
+  const int seen = visible[e / a.row_len[t]];
+  if (!seen) return;
+  const float g = a.g[t][e] * (float)seen;
   float m = a.m[t][e], v = a.v[t][e];
   m = m + (g - m) * a.omb1;
   v = v + (g * g - v) * a.omb2;

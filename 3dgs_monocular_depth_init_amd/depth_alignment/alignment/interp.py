@@ -116,15 +116,18 @@ def linear_interpolation(coords: torch.Tensor, values: torch.Tensor, config, dev
     return out.to(values.dtype)
 
 
-RBF_KERNELS = {"linear": 0, "thin_plate_spline": 1, "cubic": 2}
+# The scale-invariant kernels of torchrbf / scipy: the ones the reference's call can run at all -- it never passes
+# `epsilon`, and the library refuses every other kernel without it (gaussian, multiquadric, inverse_multiquadric,
+# inverse_quadratic), upon which the caller's `except Exception` falls back to the median scale (interp.py:345-359).
+RBF_KERNELS = {"linear": 0, "thin_plate_spline": 1, "cubic": 2, "quintic": 3}
 
 
 def rbf_interpolation(coords: torch.Tensor, values: torch.Tensor, config, device, W: int, H: int) -> torch.Tensor:
     """interp.py:30-72: RBF interpolant (kernel / smoothing of the config, polynomial of the kernel's minimum
     degree) over the pixels normalised by (W - 1, H - 1), evaluated on a grid 256 pixels wide, upsampled
     bilinearly (align_corners) to [H, W]. `gsr_rbf_fit` + `gsr_rbf_eval_grid` + `gsr_bilinear_ac_t`."""
-    if config.kernel not in RBF_KERNELS:
-        raise NotImplementedError(f"rbf kernel {config.kernel!r}: built are {sorted(RBF_KERNELS)}")
+    if config.kernel not in RBF_KERNELS:        # torchrbf's own refusal (-> the caller's median-scale fallback)
+        raise ValueError(f"`epsilon` must be specified if `kernel` is not one of {sorted(RBF_KERNELS)}; got {config.kernel!r}")
     from ..._lib import load
     lib = load()
     dev = values.device if values.is_cuda else torch.device(device)
@@ -135,7 +138,7 @@ def rbf_interpolation(coords: torch.Tensor, values: torch.Tensor, config, device
     vals = values.to(dev).float().contiguous()
     nbytes = int(lib.gsr_rbf_workspace_bytes(P))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    coeffs = torch.empty(P + 3, dtype=torch.float64, device=dev)
+    coeffs = torch.empty(P + 6, dtype=torch.float64, device=dev)
     ss = torch.empty(4, dtype=torch.float64, device=dev)
     k = RBF_KERNELS[config.kernel]
     call("gsr_rbf_fit", P, ptr(sites), ptr(vals), float(config.smoothing), k, ptr(ws), nbytes, ptr(coeffs), ptr(ss), st)
@@ -191,8 +194,6 @@ def align_depth_interpolate(predicted_depth, sfm_points_camera_coords, gt_depth,
         sfm_points_camera_coords = sfm_points_camera_coords[:, ~outlier_mask]
     try:
         scale_map = interpolate_scale(sfm_points_camera_coords, scale_factors, interp_config, device, W, H)
-    except NotImplementedError:
-        raise
     except Exception as e:  # noqa: BLE001  (reference: any failure -> median scale, interp.py:351-359)
         LOGGER.warning("Scale factor interpolation failed; using median scale instead of interpolation. %s", e)
         scale_map = scale_factors.median()

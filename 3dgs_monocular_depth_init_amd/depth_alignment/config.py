@@ -84,7 +84,8 @@ class InterpConfig:                 # config.py:113-130
     init: Optional[Literal["lstsqrs", "ransac"]] = "ransac"
     scale_outlier_removal: bool = True
     smoothing: float = 0.001
-    kernel: str = "thin_plate_spline"
+    kernel: str = "thin_plate_spline"     # linear | thin_plate_spline | cubic | quintic (the scale-invariant kernels: the call passes
+    # no `epsilon`, without which torchrbf refuses the others and the aligner falls back to the median scale)
     max_rbf_points: int = 5000
 
 

@@ -266,7 +266,12 @@ class FusedSparseAdam:
     @torch.no_grad()
     def step(self, info) -> None:
         radii = info["radii"]
-        visible = (radii > 0).all(-1).any(0).to(torch.uint8).contiguous()       # [N]: rendered by some camera
+        if radii.shape[0] > 255:
+            raise ValueError("FusedSparseAdam: at most 255 cameras per step")
+        # [N]: by how many cameras of the batch a row is rendered. The reference's sparse gradient has one entry
+        # per rendered (camera, Gaussian) pair, each carrying the row's dense gradient, and SparseAdam coalesces
+        # (sums) them (runner.py:661-672): a row seen by k cameras steps on k times its gradient.
+        visible = (radii > 0).all(-1).sum(0).to(torch.uint8).contiguous()
         rows = visible.numel()
         P, G, M, V, L, S = [], [], [], [], [], []
         beta1 = beta2 = eps = None

@@ -657,7 +657,13 @@ def rasterization(
     `_tight_tiles=True` lists a (tile, Gaussian) pair only when some pixel of the tile can
     reach alpha >= 1/255 (exact ellipse test) instead of whenever gsplat's bounding rectangle
     touches the tile: identical image and gradients, `meta["flatten_ids"]` / `isect_offsets`
-    are then a subset of gsplat's lists."""
+    are then a subset of gsplat's lists.
+
+    Size limits (checked here): C*N < 2^27 -- a pair word holds the flat (camera, Gaussian) index in 27 bits
+    beside the quadrant mask and the clamp flag; up to C*N < 2^25 (and <= 8192 buckets of 8 tiles) the bucketed
+    tile-list builder of isect_bucket.hip runs, above that the global-sort builder of isect.hip, which honours
+    `_tight_tiles` only through the masks (mask-0 pairs stay listed and are skipped by the compositing
+    kernels)."""
     if unsupported:
         raise TypeError(f"rasterization(): unsupported arguments {sorted(unsupported)}")
     if camera_model != "pinhole":
@@ -686,6 +692,9 @@ def rasterization(
     _lib.load()
 
     N, C = means.shape[0], viewmats.shape[0]
+    if C * N >= (1 << 27):
+        raise ValueError(f"rasterization(): C*N = {C * N} (camera, Gaussian) pairs; the pair words of the tile lists "
+                         "hold 27 bits (< 134 217 728). Render the cameras in smaller batches.")
     assert means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3), "shapes"
     assert opacities.shape == (N,), f"opacities {tuple(opacities.shape)}"
     assert viewmats.shape == (C, 4, 4) and Ks.shape == (C, 3, 3), "camera shapes"

@@ -403,7 +403,8 @@ int gsr_reset_opacity(int64_t n, float *logit_opacities, float *exp_avg, float *
 /* torch.optim.SparseAdam over the rows a step rendered (cfg.sparse_grad: runner.py:130 builds SparseAdam,
  * runner.py:661-672 turns every gradient into a sparse tensor over info["gaussian_ids"]): for each of the n
  * tensors [rows, row_len[t]], row r is updated iff visible[r] != 0 -- parameter and both moments; all other
- * rows are untouched. step_size[t] = lr sqrt(1 - beta2^t) / (1 - beta1^t); the arithmetic order is
+ * rows are untouched. visible[r] = the number of cameras that render row r (<= 255): the row steps on that
+ * many times its dense gradient, as SparseAdam's coalesce() of the per-(camera, Gaussian) entries does. step_size[t] = lr sqrt(1 - beta2^t) / (1 - beta1^t); the arithmetic order is
  * torch/optim/_functional.py sparse_adam's. HOST pointer arrays, n <= 8. */
 int gsr_sparse_adam_step(int n, int64_t rows, const uint8_t *visible, void *const *params,
                          const void *const *grads, void *const *exp_avg, void *const *exp_avg_sq,

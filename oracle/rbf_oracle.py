@@ -14,8 +14,9 @@ ports line by line:
     f(x) = K(x eps, y eps) @ coeffs[:P] + P((x - shift)/scale) @ coeffs[P:]
 
 with the kernel functions (as scipy's `_rbfinterp_pythran.py`) linear -r, thin_plate_spline r^2 log r
-(0 at r = 0), cubic r^3; degree = the kernel's minimum degree (0, 1, 1); epsilon = 1 (scale-invariant
-kernels); monomials in scipy's order [1, x, y].
+(0 at r = 0), cubic r^3, quintic -r^5; degree = the kernel's minimum degree (0, 1, 1, 2); epsilon = 1
+(these are the scale-invariant kernels, the only ones usable without `epsilon`, which the reference's call
+never passes); monomials in scipy's order [1, x, y, x^2, x y, y^2] (`_monomial_powers`).
 
 PARITY: unpinned against torchrbf (absent). Pinned against scipy.interpolate.RBFInterpolator itself -- the
 library torchrbf ports -- in tests/test_rbf.py (float64). The reference runs torchrbf in float32; this
@@ -25,8 +26,8 @@ from __future__ import annotations
 
 import numpy as np
 
-KERNELS = {"linear": 0, "thin_plate_spline": 1, "cubic": 2}
-MIN_DEGREE = {"linear": 0, "thin_plate_spline": 1, "cubic": 1}
+KERNELS = {"linear": 0, "thin_plate_spline": 1, "cubic": 2, "quintic": 3}
+MIN_DEGREE = {"linear": 0, "thin_plate_spline": 1, "cubic": 1, "quintic": 2}
 
 
 def _phi(r: np.ndarray, kernel: str) -> np.ndarray:
@@ -34,6 +35,8 @@ def _phi(r: np.ndarray, kernel: str) -> np.ndarray:
         return -r
     if kernel == "cubic":
         return r ** 3
+    if kernel == "quintic":
+        return -r ** 5
     if kernel == "thin_plate_spline":
         with np.errstate(divide="ignore", invalid="ignore"):
             return np.where(r == 0.0, 0.0, r * r * np.log(r))
@@ -44,6 +47,8 @@ def _poly(x: np.ndarray, degree: int) -> np.ndarray:
     cols = [np.ones(len(x))]
     if degree >= 1:
         cols += [x[:, 0], x[:, 1]]
+    if degree >= 2:
+        cols += [x[:, 0] ** 2, x[:, 0] * x[:, 1], x[:, 1] ** 2]
     return np.stack(cols, 1)
 
 

@@ -85,3 +85,12 @@ def test_gsplat_shim_exports_what_the_reference_imports():
         sys.path.remove(shims)
         for name in [n for n in sys.modules if n == "gsplat" or n.startswith("gsplat.")]:
             del sys.modules[name]
+
+
+def test_product_library_reads_no_environment_variables():
+    """The A/B scaffolding (occupancy padding, GEMM core selection) is compiled in only with
+    -DGSR_EXPERIMENT_KNOBS (tools/build_variants.sh): the product's entry points never call getenv."""
+    import subprocess
+    lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    out = subprocess.run(["nm", "-D", "-u", str(lib._LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out

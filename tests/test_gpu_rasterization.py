@@ -259,6 +259,31 @@ def test_long_tile_lists(R):
     _check(cpu, gpu, out_c, out_g)
 
 
+@pytest.mark.parametrize("tight", [False, True])
+def test_needle_gaussians_tight_lists_vs_oracle(R, tight):
+    """Strongly anisotropic, randomly rotated Gaussians (axis ratio 100-300: 2-D conic eigenvalues orders of
+    magnitude apart) under tight lists: the exact pair test's edge constants kx = det / 2c, ky = det / 2a come
+    from a compensated determinant (raster_common.h make_pair_conic); with the plain a - b^2/c a marginally
+    visible pair or quadrant could be dropped. Image and gradients against the oracle, and the
+    tight lists against the exact masks."""
+    N = 900
+    g = torch.Generator().manual_seed(21)
+    sc = scenes.make_scene(N, 21, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    long_axis = torch.randint(0, 3, (N,), generator=g)
+    scales = torch.full((N, 3), 0.0012) * (0.5 + torch.rand(N, 3, generator=g))
+    scales[torch.arange(N), long_axis] = 0.08 + 0.25 * torch.rand(N, generator=g)
+    sc["scales"] = scales
+    sc["quats"] = torch.randn(N, 4, generator=g)
+    sc["opacities"] = 0.3 + 0.69 * torch.rand(N, generator=g)
+    W, H = 128, 96
+    vm, K = scenes.cameras([5], width=W, height=H, f=120.0, dist=2.5)
+    cpu, gpu, out_c, out_g = _run_both(R, sc, vm, K, W, H, tight=tight)
+    _check(cpu, gpu, out_c, out_g)
+    a, b, c = out_g[2]["conics"].detach()[0].unbind(-1)
+    ratio = ((a + c) / 2 + ((a - c) ** 2 / 4 + b * b).sqrt()) / ((a + c) / 2 - ((a - c) ** 2 / 4 + b * b).sqrt()).clamp_min(1e-12)
+    assert float(ratio[(out_g[2]["radii"][0] > 0).all(-1)].median()) > 30.0        # needles on screen, too
+
+
 @pytest.mark.parametrize("antialiased", [False, True])
 @pytest.mark.parametrize("cams", [[0], [0, 40]])
 def test_runner_rasterize_splats_fused_activations(R, antialiased, cams):

@@ -21,7 +21,7 @@ def _problem(P, W, H, seed):
     return xy, vals.astype(np.float32)
 
 
-@pytest.mark.parametrize("kernel", ["thin_plate_spline", "linear", "cubic"])
+@pytest.mark.parametrize("kernel", ["thin_plate_spline", "linear", "cubic", "quintic"])
 def test_oracle_equals_scipy_rbf_interpolator(kernel):
     from scipy.interpolate import RBFInterpolator
     rng = np.random.default_rng(0)
@@ -40,7 +40,8 @@ def test_oracle_bilinear_equals_torch_align_corners():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel,P,W,H", [("thin_plate_spline", 700, 640, 360), ("thin_plate_spline", 3, 100, 80),
-                                          ("linear", 300, 300, 200), ("cubic", 257, 512, 384)])
+                                          ("linear", 300, 300, 200), ("cubic", 257, 512, 384),
+                                          ("quintic", 400, 480, 320)])
 def test_hip_rbf_interpolation_equals_oracle(kernel, P, W, H):
     I = importlib.import_module("3dgs_monocular_depth_init_amd.depth_alignment.alignment.interp")
     xy, vals = _problem(P, W, H, P)
@@ -69,3 +70,14 @@ def test_hip_rbf_full_size_system_and_point_subset():
     assert torch.isfinite(got).all()
     at = got[torch.from_numpy(xy[1]).cuda(), torch.from_numpy(xy[0]).cuda()].cpu().numpy()
     assert np.abs(at - vals).max() < 0.05 and np.abs(at - vals).mean() < 5e-3      # smooth field, grid 256 wide
+
+
+@pytest.mark.gpu
+def test_kernels_that_need_epsilon_take_the_median_fallback():
+    """torchrbf (like scipy) refuses the shape-parameter kernels without `epsilon`, and the reference's call never
+    passes one (interp.py:44-50): its `except Exception` then uses the median scale (interp.py:345-359). Same here."""
+    I = importlib.import_module("3dgs_monocular_depth_init_amd.depth_alignment.alignment.interp")
+    cfg = SimpleNamespace(method="rbf", kernel="gaussian", smoothing=0.001)
+    xy, vals = _problem(50, 64, 48, 3)
+    with pytest.raises(ValueError, match="epsilon"):
+        I.interpolate_scale(torch.from_numpy(xy).cuda(), torch.from_numpy(vals).cuda(), cfg, "cuda", 64, 48)

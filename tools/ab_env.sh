@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the LDS-pad / GEMM-core variables are read only by a library built with -DGSR_EXPERIMENT_KNOBS=1:
+#  bash tools/build_variants.sh knobs "-DGSR_EXPERIMENT_KNOBS=1"; GSRAST_LIB=.../libgsrast_knobs.so)
 # A/B of environment switches inside ONE gpurun call (box-to-box variation is ~3-5 %):
 #   bash tools/ab_env.sh "name1:VAR=1 VAR2=x" "name2:" ...      (each twice, interleaved)
 set -uo pipefail
