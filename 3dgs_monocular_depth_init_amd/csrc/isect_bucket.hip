@@ -548,10 +548,23 @@ __device__ unsigned long long *g_sort_timeline = nullptr;
 #define SORT_STAMP(k)
 #endif
 // Pass 3: one workgroup per bucket. The bucket's region holds its listed pairs (and, for tight
-// lists, sentinels in the slots the rectangle rule reserved for dropped pairs). The real keys are
-// split by tile-in-bucket while they are loaded into LDS (8-bin counting sort), then the 8 tile
-// segments are depth-sorted side by side, each by its own 128-thread group; the lists are written
+// lists, sentinels in the slots the rectangle rule reserved for dropped pairs); the lists are written
 // COMPACTED: the bucket's output position is the sum of the real counts of the buckets before it.
+//
+// Round 4: the depth sort is no longer a network. Round 3's kernel split the keys by tile (8 segments) and
+// ran a bitonic network on each: 45-55 compare-exchange steps, every one an LDS read -> compare -> LDS
+// write -> sync round trip, 76 % of a workgroup's 26.6 us (profiles/r03_sort_timeline.json). Now the
+// keys are split ONCE by (tile, depth bin) -- the bin a monotone function of the depth bits over the
+// bucket's own [min, max], with about eight keys per bin -- and every key then finds its rank inside
+// its bin by comparing with the bin's few members: position = bin start + rank. Bins are ordered by
+// (tile, depth) and the in-bin rank uses the whole composite key, so the result is exactly the order of
+// the full sort. A bucket in which some bin holds more than BK_BIN_MAX keys (many equal depths) takes the
+// round-3 networks on the tile segments instead (which the split has already laid out).
+constexpr int BK_MAX_BINS = 1024;      // 8 tiles x up to 128 depth bins
+constexpr int BK_BIN_TARGET = 8;       // keys per bin aimed at
+constexpr int BK_BIN_MAX = 160;        // longer bins: fall back to the networks
+constexpr int BK_KPT = BK_SORT_CAP / BK_THREADS;   // keys per thread when a whole bucket is in flight (8)
+
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
                    const int32_t *__restrict__ bucket_order, const int32_t *__restrict__ real_counts,
@@ -560,8 +573,11 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
                    int32_t *__restrict__ tile_offsets, int n_tiles, int capacity,
                    int32_t *__restrict__ clear_counts, int32_t *__restrict__ total_host) {
   __shared__ uint64_t sk[BK_SORT_CAP];
-  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], seg_cur[BK_TILES], npad_max_s;
-  __shared__ int32_t red[BK_THREADS / 64], out_base_s;
+  __shared__ int32_t bins[BK_MAX_BINS + 8], cur[BK_MAX_BINS];
+  __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
+  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s;
+  __shared__ int32_t red[BK_THREADS / 64], out_base_s, maxbin_s;
+  __shared__ uint32_t dmin_s, dmax_s;
   const int tid = threadIdx.x;
   SORT_STAMP(0);
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
@@ -571,43 +587,94 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   const int s = min(bucket_offsets[b], capacity), e = min(bucket_offsets[b + 1], capacity);
   const int LA = e - s;                               // slots of the region (real keys + sentinels)
   const int row = b / bw, bx = b - row * bw;          // row = cam*tile_h + ty
-  // output position of this bucket: real pairs of all buckets before it
+  const int Lr = real_counts[b];                      // listed pairs (sizes the bins; the lists use what the keys say)
+  // the bucket's keys: in registers when the region fits (one global read), else re-read per pass
+  const bool in_regs = LA <= BK_SORT_CAP;
+  uint64_t kreg[BK_KPT];
+  uint32_t mn = 0xffffffffu, mx = 0u;
+  if (in_regs) {
+#pragma unroll
+    for (int u = 0; u < BK_KPT; ++u) {
+      const int t = tid + u * BK_THREADS;
+      kreg[u] = t < LA ? keys[s + t] : BK_SENTINEL;
+    }
+  }
+  auto depth_of = [](uint64_t k) { return (uint32_t)(k >> 30) & 0x7fffffffu; };
+  auto for_keys = [&](auto &&f) {
+    if (in_regs) {
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u)
+        if (kreg[u] != BK_SENTINEL) f(kreg[u]);
+    } else {
+      for (int t = tid; t < LA; t += BK_THREADS) {
+        const uint64_t k = keys[s + t];
+        if (k != BK_SENTINEL) f(k);
+      }
+    }
+  };
+  // output position of this bucket: real pairs of all buckets before it; and the depth range of its keys
   {
     int acc = 0;
     for (int i = tid; i < b; i += BK_THREADS) acc += real_counts[i];
     acc = wave_sum_i32(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
-    if (tid < BK_TILES) seg_cnt[tid] = 0;
+    if (tid == 0) {
+      dmin_s = 0xffffffffu;
+      dmax_s = 0u;
+      maxbin_s = 0;
+    }
+    for (int i = tid; i < BK_MAX_BINS + 8; i += BK_THREADS) bins[i] = 0;
     __syncthreads();
     if (tid == 0) {
       int t = 0;
       for (int w = 0; w < BK_THREADS / 64; ++w) t += red[w];
       out_base_s = t;
     }
+    for_keys([&](uint64_t k) {
+      const uint32_t d = depth_of(k);
+      mn = min(mn, d);
+      mx = max(mx, d);
+    });
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    }
+    if ((tid & 63) == 0 && mn <= mx) {
+      atomicMin(&dmin_s, mn);
+      atomicMax(&dmax_s, mx);
+    }
+    __syncthreads();
   }
   SORT_STAMP(1);
-  for (int t = tid; t < LA; t += BK_THREADS) {
-    const uint64_t k = keys[s + t];
-    if (k != BK_SENTINEL) atomicAdd(&seg_cnt[(int)(k >> 61)], 1);
-  }
+  const int out_base = out_base_s;
+  // depth bins per tile: about BK_BIN_TARGET keys per (tile, bin) if depths were uniform over [min, max]
+  int NB = (Lr + BK_TILES * BK_BIN_TARGET - 1) / (BK_TILES * BK_BIN_TARGET);
+  NB = max(1, min(NB, BK_MAX_BINS / BK_TILES));
+  const float fmin = __uint_as_float(dmin_s), fmax = __uint_as_float(dmax_s);   // depths are positive floats
+  const float span = fmax - fmin;
+  const float bscale = span > 0.f ? (float)NB / span : 0.f;
+  // monotone in the depth bits: float subtraction and multiplication by a positive constant round
+  // monotonically, truncation is monotone, the clamp keeps the top edge inside
+  auto bin_of = [&](uint64_t k) {
+    const float d = __uint_as_float(depth_of(k));
+    const int db = min(NB - 1, (int)((d - fmin) * bscale));
+    return (int)(k >> 61) * NB + db;
+  };
+  const int nbins = BK_TILES * NB;
+  for_keys([&](uint64_t k) { atomicAdd(&bins[bin_of(k)], 1); });
   __syncthreads();
   SORT_STAMP(2);
-  const int out_base = out_base_s;
-  if (tid == 0) {
-    int run = 0, mx = 0;
-    for (int q = 0; q < BK_TILES; ++q) {
-      seg_start[q] = run;
-      seg_cur[q] = run;
-      run += seg_cnt[q];
-      mx = max(mx, seg_cnt[q]);
-    }
-    seg_start[BK_TILES] = run;
-    int np = 1;
-    while (np < mx) np <<= 1;
-    npad_max_s = np;
+  {
+    int m = 0;
+    for (int i = tid; i < nbins; i += BK_THREADS) m = max(m, bins[i]);
+    m = wave_max_i32(m);
+    if ((tid & 63) == 0 && m > 0) atomicMax(&maxbin_s, m);
   }
+  const int L = bk_block_exclusive_scan(bins, nbins, wave_tot);   // bins = start of every (tile, depth bin); L = real pairs
+  if (tid == 0) bins[nbins] = L;
+  for (int i = tid; i < nbins; i += BK_THREADS) cur[i] = bins[i];
   __syncthreads();
-  const int L = seg_start[BK_TILES];                  // real pairs of this bucket
   auto put = [&](int t, uint64_t k) {
     const int64_t o = (int64_t)out_base + t;
     if (o < capacity) {
@@ -617,14 +684,50 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     }
   };
   if (L <= BK_SORT_CAP) {
-    for (int t = tid; t < LA; t += BK_THREADS) {
-      const uint64_t k = keys[s + t];
-      if (k != BK_SENTINEL) sk[atomicAdd(&seg_cur[(int)(k >> 61)], 1)] = k;
-    }
+    for_keys([&](uint64_t k) { sk[atomicAdd(&cur[bin_of(k)], 1)] = k; });
     __syncthreads();
     SORT_STAMP(3);
-    const int grp = tid >> 7;                          // 8 groups of 128 threads
-    bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+    if (maxbin_s <= BK_BIN_MAX) {
+      // every key's rank inside its bin (ranks first, from the unmodified split; then the permutation in place)
+      uint64_t mine[BK_KPT];
+      int dst[BK_KPT];
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u) {
+        const int p = tid + u * BK_THREADS;
+        dst[u] = -1;
+        if (p < L) {
+          const uint64_t k = sk[p];
+          const int bn = bin_of(k);
+          const int s0 = bins[bn], e0 = bins[bn + 1];
+          int rank = 0;
+          for (int j = s0; j < e0; ++j) rank += sk[j] < k ? 1 : 0;
+          mine[u] = k;
+          dst[u] = s0 + rank;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u)
+        if (dst[u] >= 0) sk[dst[u]] = mine[u];
+      __syncthreads();
+    } else {
+      // many equal depths in one bin: the round-3 networks on the eight tile segments the split has laid out
+      if (tid < BK_TILES) {
+        seg_start[tid] = bins[tid * NB];
+        seg_cnt[tid] = bins[(tid + 1) * NB] - bins[tid * NB];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int mxs = 0;
+        for (int q = 0; q < BK_TILES; ++q) mxs = max(mxs, seg_cnt[q]);
+        int np = 1;
+        while (np < mxs) np <<= 1;
+        npad_max_s = np;
+      }
+      __syncthreads();
+      const int grp = tid >> 7;                          // 8 groups of 128 threads
+      bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+    }
     SORT_STAMP(4);
     for (int t = tid; t < L; t += BK_THREADS) put(t, sk[t]);
     SORT_STAMP(5);
@@ -634,7 +737,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);
   }
   if (tid < BK_TILES && bx * BK_TILES + tid < tile_w)
-    tile_offsets[row * tile_w + bx * BK_TILES + tid] = min(out_base + seg_start[tid], capacity);
+    tile_offsets[row * tile_w + bx * BK_TILES + tid] = min(out_base + bins[tid * NB], capacity);
   if (b == n_buckets - 1 && tid == 0) {
     tile_offsets[n_tiles] = min(out_base + L, capacity);
     if (total_host)
