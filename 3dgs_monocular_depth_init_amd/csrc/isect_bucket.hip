@@ -561,7 +561,10 @@ __device__ unsigned long long *g_sort_timeline = nullptr;
 // the full sort. A bucket in which some bin holds more than BK_BIN_MAX keys (many equal depths) takes the
 // round-3 networks on the tile segments instead (which the split has already laid out).
 constexpr int BK_MAX_BINS = 1024;      // 8 tiles x up to 128 depth bins
-constexpr int BK_BIN_TARGET = 8;       // keys per bin aimed at
+#ifndef GSR_BIN_TARGET
+#define GSR_BIN_TARGET 4
+#endif
+constexpr int BK_BIN_TARGET = GSR_BIN_TARGET;   // keys per bin aimed at
 constexpr int BK_BIN_MAX = 160;        // longer bins: fall back to the networks
 constexpr int BK_KPT = BK_SORT_CAP / BK_THREADS;   // keys per thread when a whole bucket is in flight (8)
 

@@ -82,18 +82,31 @@ class Metric3d(DepthPredictor):
     def name(self) -> str:
         return self.__name
 
+    batch_size = 4      # images per network call in predict_depths (the init loop predicts every training image)
+
     @torch.no_grad()
     def predict_depth(self, img: torch.Tensor, intrinsics: CameraIntrinsics) -> PredictedDepth:
-        img = img.to(self.device)
-        H, W = img.shape[:2]
-        rgb, pad_info, scale = preprocess(img)
-        pred_depth, confidence, output_dict = self.__model.inference({"input": rgb})
-        normal = output_dict["prediction_normal"]
-        fx_scaled = intrinsics.fx * scale                                   # :54-59
-        depth = to_og_size(pred_depth.squeeze(), pad_info, (H, W),
-                           scale=fx_scaled / CANONICAL_FOCAL, clamp=(0.0, 300.0))   # :127-131
-        conf = to_og_size(confidence.squeeze(), pad_info, (H, W))
-        n = torch.stack([to_og_size(normal[0, k], pad_info, (H, W)) for k in range(3)], dim=-1)
-        n_conf = to_og_size(normal[0, 3], pad_info, (H, W))
-        return PredictedDepth(depth=depth, mask=torch.ones_like(depth, dtype=torch.bool),
-                              depth_confidence=conf, normal=n, normal_confidence=n_conf)
+        return self.predict_depths([img], [intrinsics])[0]
+
+    @torch.no_grad()
+    def predict_depths(self, imgs, intrinsics) -> list:
+        """predict_depth (metric3d.py:38-139) for a list of images, `batch_size` of them per network call
+        (metric3d_net: one batched encoder pass, the decoders as parallel branches of one HIP graph)."""
+        out = []
+        for a in range(0, len(imgs), self.batch_size):
+            chunk = [im.to(self.device) for im in imgs[a:a + self.batch_size]]
+            pre = [preprocess(im) for im in chunk]
+            rgb = pre[0][0] if len(pre) == 1 else torch.cat([p[0] for p in pre], 0)
+            pred_depth, confidence, output_dict = self.__model.inference({"input": rgb})
+            normal = output_dict["prediction_normal"]
+            for i, (im, (_, pad_info, scale)) in enumerate(zip(chunk, pre)):
+                H, W = im.shape[:2]
+                fx_scaled = intrinsics[a + i].fx * scale                            # :54-59
+                depth = to_og_size(pred_depth[i, 0], pad_info, (H, W),
+                                   scale=fx_scaled / CANONICAL_FOCAL, clamp=(0.0, 300.0))   # :127-131
+                conf = to_og_size(confidence[i, 0], pad_info, (H, W))
+                n = torch.stack([to_og_size(normal[i, k], pad_info, (H, W)) for k in range(3)], dim=-1)
+                n_conf = to_og_size(normal[i, 3], pad_info, (H, W))
+                out.append(PredictedDepth(depth=depth, mask=torch.ones_like(depth, dtype=torch.bool),
+                                          depth_confidence=conf, normal=n, normal_confidence=n_conf))
+        return out

@@ -16,6 +16,14 @@ Weights are taken from a state dict with the reference's own parameter names (pr
 `encoder.` / `decoder.`), so a real checkpoint loads unchanged; none is available offline, the
 tests use deterministic random weights.
 
+Batches (round 4): `inference({"input": rgb [B,3,H,W]})` runs the ENCODER over all B images at once -- every
+Linear is one GEMM over B x 3349 token rows (a full grid for the 256 x 256 eight-phase core where one image
+leaves proj / fc2 56 tiles), attention per image -- and the B DECODERS as parallel branches of one HIP graph,
+each on its own stream with its own scratch maps: the decoder is ~370 short dependent launches per image whose
+gaps and partly filled grids overlap across the branches. Nothing forces batch 1 behind the reference's
+`Metric3d.predict_depth`: the init loop (monocular_depth_init.py:149-156) predicts every training image, and
+`Metric3d.predict_depths` hands them over B at a time. B = 1 issues exactly the launches of rounds 2-3.
+
 Everything heavy runs in csrc/depthnet.hip through the C ABI: every Linear / convolution is the
 fp16 MFMA GEMM `gsr_dn_gemm` (3x3 convolutions through `gsr_dn_im2col` rows), attention is
 `gsr_dn_attention`; torch allocates buffers and, once at construction, re-lays the weights
@@ -124,8 +132,10 @@ class Metric3DNet:
                  input_size: Tuple[int, int] = (616, 1064), config: Optional[dict] = None,
                  use_graph: bool = True):
         load()
-        self.use_graph = use_graph      # replay one captured HIP graph per image (see inference)
-        self._graph = None
+        self.use_graph = use_graph      # replay one captured HIP graph per batch size (see inference)
+        self._graphs: Dict[int, tuple] = {}
+        self._branch = 0                # decoder branch whose scratch maps are in use (parallel branches of one graph)
+        self._side: List[torch.cuda.Stream] = []
         cfg = dict(CONFIGS[backbone]) if config is None else dict(config)
         self.cfg, self.dev = cfg, torch.device(device)
         self.H, self.W = input_size
@@ -238,6 +248,7 @@ class Metric3DNet:
 
     # ------------------------------------------------------------------ primitives
     def _buf(self, key, shape, dtype=torch.float16, zero=False):
+        key = (getattr(self, "_branch", 0), key)
         t = self._scratch.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             t = torch.zeros(*shape, dtype=dtype, device=self.dev)
@@ -308,47 +319,55 @@ class Metric3DNet:
     # ------------------------------------------------------------------ encoder
     @torch.no_grad()
     def encode(self, img: torch.Tensor) -> torch.Tensor:
-        """img fp32 [1,3,H,W] -> final-norm tokens fp16 [n_tok, D] (forward_features, :962-1004)."""
+        """img fp32 [B,3,H,W] -> final-norm tokens fp16 [n_tok, D] (B = 1) or [B, n_tok, D]
+        (forward_features, :962-1004). Linears and LayerNorms run over all B * n_tok rows, attention and
+        the patch embedding per image."""
         D, n_tok, npatch = self.D, self.n_tok, self.gh * self.gw
         img = img.to(device=self.dev, dtype=torch.float32).contiguous()
-        assert img.shape == (1, 3, self.H, self.W), tuple(img.shape)
-        rows = self._buf("patch_rows", (npatch, self.patch.kp))
-        call("gsr_dn_patch_rows", self.H, self.W, PATCH, self.patch.kp, ptr(img), ptr(rows), _st())
-        x = self._buf("x", (n_tok, D), torch.float32)                       # residual stream, fp32
-        x[:1 + N_REG].copy_(self.tok_head)
-        xp = x[1 + N_REG:]
-        self.gemm(npatch, self.patch, rows, self.patch.kp, residual=self.pos_patch, ldr=D, out32=xp, ldo32=D)
-        xn = self._buf("xn", (n_tok, D))
-        qkv = self._buf("qkv", (n_tok, 3 * D))
-        att = self._buf("att", (n_tok, D))
+        assert img.dim() == 4 and img.shape[1:] == (3, self.H, self.W), tuple(img.shape)
+        B = img.shape[0]
+        M = B * n_tok
+        rows = self._buf("patch_rows", (B * npatch, self.patch.kp))
+        x = self._buf("x", (M, D), torch.float32)                           # residual stream, fp32
+        for i in range(B):
+            call("gsr_dn_patch_rows", self.H, self.W, PATCH, self.patch.kp, ptr(img[i]), ptr(rows[i * npatch:]), _st())
+            xi = x[i * n_tok:(i + 1) * n_tok]
+            xi[:1 + N_REG].copy_(self.tok_head)
+            self.gemm(npatch, self.patch, rows[i * npatch:], self.patch.kp, residual=self.pos_patch, ldr=D,
+                      out32=xi[1 + N_REG:], ldo32=D)
+        xn = self._buf("xn", (M, D))
+        qkv = self._buf("qkv", (M, 3 * D))
+        att = self._buf("att", (M, D))
         swiglu = bool(self.blocks) and "w12" in self.blocks[0]
         h_ffn = self.blocks[0]["w3"].k if swiglu else 4 * D
-        hid = self._buf("hid", (n_tok, _ceil(h_ffn, 64)))
-        h12 = self._buf("h12", (n_tok, 2 * h_ffn)) if swiglu else None
+        hid = self._buf("hid", (M, _ceil(h_ffn, 64)))
+        h12 = self._buf("h12", (M, 2 * h_ffn)) if swiglu else None
         n_pad = _ceil(n_tok, 64)
         vt = self._buf("vt", (self.heads * 64 * n_pad,))
         scale = 64 ** -0.5
         for b in self.blocks:
-            call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n1w"]), ptr(b["n1b"]), 1e-6, ptr(xn), D,
+            call("gsr_dn_layernorm", M, D, ptr(x), D, 0, ptr(b["n1w"]), ptr(b["n1b"]), 1e-6, ptr(xn), D,
                  None, 0, 0, _st())
-            self.gemm(n_tok, b["qkv"], xn, D, out16=qkv, ldo16=3 * D)
+            self.gemm(M, b["qkv"], xn, D, out16=qkv, ldo16=3 * D)
             if getattr(self, "flop_count", None) is not None:
-                self.flop_count += 4.0 * n_tok * n_tok * D
-            call("gsr_dn_attention", n_tok, n_pad, self.heads, ptr(qkv), 3 * D, ptr(vt), scale, ptr(att), D, _st())
-            self.gemm(n_tok, b["proj"], att, D, gamma=b["ls1"], residual=x, ldr=D, out32=x, ldo32=D)
-            call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(b["n2w"]), ptr(b["n2b"]), 1e-6, ptr(xn), D,
+                self.flop_count += 4.0 * B * n_tok * n_tok * D
+            for i in range(B):      # (same stream: the launches share the transposed-V scratch in order)
+                call("gsr_dn_attention", n_tok, n_pad, self.heads, ptr(qkv[i * n_tok:]), 3 * D, ptr(vt), scale,
+                     ptr(att[i * n_tok:]), D, _st())
+            self.gemm(M, b["proj"], att, D, gamma=b["ls1"], residual=x, ldr=D, out32=x, ldo32=D)
+            call("gsr_dn_layernorm", M, D, ptr(x), D, 0, ptr(b["n2w"]), ptr(b["n2b"]), 1e-6, ptr(xn), D,
                  None, 0, 0, _st())
             if swiglu:
-                self.gemm(n_tok, b["w12"], xn, D, out16=h12, ldo16=2 * h_ffn)
-                call("gsr_dn_swiglu", n_tok, h_ffn, ptr(h12), 2 * h_ffn, ptr(hid), hid.shape[1], _st())
-                self.gemm(n_tok, b["w3"], hid, hid.shape[1], gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
+                self.gemm(M, b["w12"], xn, D, out16=h12, ldo16=2 * h_ffn)
+                call("gsr_dn_swiglu", M, h_ffn, ptr(h12), 2 * h_ffn, ptr(hid), hid.shape[1], _st())
+                self.gemm(M, b["w3"], hid, hid.shape[1], gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
             else:
-                self.gemm(n_tok, b["fc1"], xn, D, act=ACT_GELU, out16=hid, ldo16=4 * D)
-                self.gemm(n_tok, b["fc2"], hid, 4 * D, gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
-        tokens = torch.empty(n_tok, D, dtype=torch.float16, device=self.dev)
-        call("gsr_dn_layernorm", n_tok, D, ptr(x), D, 0, ptr(self.norm_w), ptr(self.norm_b), 1e-6, ptr(tokens), D,
+                self.gemm(M, b["fc1"], xn, D, act=ACT_GELU, out16=hid, ldo16=4 * D)
+                self.gemm(M, b["fc2"], hid, 4 * D, gamma=b["ls2"], residual=x, ldr=D, out32=x, ldo32=D)
+        tokens = torch.empty(M, D, dtype=torch.float16, device=self.dev)
+        call("gsr_dn_layernorm", M, D, ptr(x), D, 0, ptr(self.norm_w), ptr(self.norm_b), 1e-6, ptr(tokens), D,
              None, 0, 0, _st())
-        return tokens
+        return tokens if B == 1 else tokens.view(B, n_tok, D)
 
     # ------------------------------------------------------------------ decoder pieces
     def _readout(self, tokens, i) -> Map:
@@ -418,7 +437,7 @@ class Metric3DNet:
             # torch.cat([h, x]) / torch.cat([r * h, x]) as virtual concatenations (`gsr_dn_conv_gemm2`): the
             # convolutions read h / r*h in place of the first C input channels -- no copy of the hidden state
             # into the concatenated input, and the input map (zero channels behind Cin) is allocated once
-            key = (g, h.H, h.W)
+            key = (getattr(self, "_branch", 0), g, h.H, h.W)
             bufs = self._gru_bufs.get(key)
             if bufs is None:
                 hx = Map(h.H, h.W, Cin, self.dev, ld=max(cin_p, _cpad(Cin)))
@@ -450,9 +469,10 @@ class Metric3DNet:
             return
         # (channel counts that are not multiples of 64 -- Metric3D-small: the concatenated input is a real
         # copy; its map is allocated and zeroed ONCE per level, every call overwrites all Cin channels)
-        hx = self._gru_bufs.get((g, h.H, h.W, "copy"))
+        kc = (getattr(self, "_branch", 0), g, h.H, h.W, "copy")
+        hx = self._gru_bufs.get(kc)
         if hx is None:
-            hx = self._gru_bufs[(g, h.H, h.W, "copy")] = Map(h.H, h.W, Cin, self.dev)
+            hx = self._gru_bufs[kc] = Map(h.H, h.W, Cin, self.dev)
         self.copy(h, hx.chan(0, C))
         c0 = C
         for ch, produce in xs:
@@ -584,30 +604,61 @@ class Metric3DNet:
 
     @torch.no_grad()
     def _run(self, img):
-        return self.decode(self.encode(img))
+        """encode + decode of a batch [B,3,H,W]: the B decoders on their own streams (forked from and joined
+        to the current one, so that a graph capture records them as parallel branches)."""
+        B = img.shape[0]
+        tokens = self.encode(img)
+        if B == 1:
+            self._branch = 0
+            return self.decode(tokens)
+        main = torch.cuda.current_stream()
+        while len(self._side) < B - 1:
+            self._side.append(torch.cuda.Stream(device=self.dev))
+        encoded = torch.cuda.Event()
+        encoded.record(main)                    # the branches depend on the encoder alone, not on each other
+        outs = [None] * B
+        try:
+            for b in range(1, B):
+                self._branch = b
+                st = self._side[b - 1]
+                st.wait_event(encoded)
+                with torch.cuda.stream(st):
+                    outs[b] = self.decode(tokens[b])
+            self._branch = 0
+            outs[0] = self.decode(tokens[0])
+        finally:
+            self._branch = 0
+        for st in self._side[:B - 1]:
+            main.wait_stream(st)
+        return tuple(torch.cat([o[k] for o in outs], 0) for k in range(3))
 
     @torch.no_grad()
     def inference(self, data: Dict[str, torch.Tensor]):
-        """`model.inference({"input": rgb})` of metric3d.py:87-88. One image is ~600 (ViT-S) to
+        """`model.inference({"input": rgb})` of metric3d.py:87-88, rgb [B,3,H,W]. One image is ~600 (ViT-S) to
         ~900 (ViT-L) short launches whose host side (ctypes + allocator) takes longer than the
         GPU work of the decoder, so after a first eager pass the whole forward is captured in ONE
-        HIP graph (fixed input size -> fixed buffers) and replayed per image."""
+        HIP graph per batch size (fixed input size -> fixed buffers) and replayed per batch."""
         img = data["input"].to(device=self.dev, dtype=torch.float32)
+        if img.dim() == 3:
+            img = img[None]
+        B = img.shape[0]
         if not self.use_graph:
             depth, conf, normal = self._run(img)
         else:
-            if self._graph is None:
-                self._g_in = img.clone().contiguous()
+            entry = self._graphs.get(B)
+            if entry is None:
+                g_in = img.clone().contiguous()
                 side = torch.cuda.Stream(device=self.dev)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    self._run(self._g_in)                       # eager pass: sizes every scratch buffer
+                    self._run(g_in)                             # eager pass: sizes every scratch buffer
                 torch.cuda.current_stream().wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._g_out = self._run(self._g_in)
-                self._graph = g
-            self._g_in.copy_(img)
-            self._graph.replay()
-            depth, conf, normal = (t.clone() for t in self._g_out)
+                    g_out = self._run(g_in)
+                entry = self._graphs[B] = (g, g_in, g_out)
+            g, g_in, g_out = entry
+            g_in.copy_(img)
+            g.replay()
+            depth, conf, normal = (t.clone() for t in g_out)
         return depth, conf, {"prediction_normal": normal, "prediction": depth, "confidence": conf}

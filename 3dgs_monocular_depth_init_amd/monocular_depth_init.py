@@ -83,6 +83,34 @@ def predict_depth_or_get_cached_depth(model: DepthPredictor, image: torch.Tensor
     return depth
 
 
+def _with_predicted_depths(entries, model, device, get_image, get_K, cached=None):
+    """Yield (entry, PredictedDepth) over `entries`, `model.batch_size` images per network call when the predictor
+    has `predict_depths` (Metric3d: one batched encoder pass + parallel decoder branches), else one at a time --
+    the reference's loop (monocular_depth_init.py:120-147) predicts every training image one by one, but nothing
+    in it depends on that. `cached(entry)` may return a stored PredictedDepth (or None)."""
+    bs = max(1, int(getattr(model, "batch_size", 1))) if hasattr(model, "predict_depths") else 1
+    group = []
+
+    def flush():
+        todo = [(i, e) for i, (e, d) in enumerate(group) if d is None]
+        if todo:
+            if bs > 1:
+                preds = model.predict_depths([get_image(e) for _, e in todo], [CameraIntrinsics(get_K(e)) for _, e in todo])
+            else:
+                preds = [model.predict_depth(get_image(e), CameraIntrinsics(get_K(e))) for _, e in todo]
+            for (i, e), pd in zip(todo, preds):
+                group[i] = (e, pd)
+        out = list(group)
+        group.clear()
+        return out
+
+    for e in entries:
+        group.append((e, cached(e) if cached is not None else None))
+        if sum(1 for _, d in group if d is None) >= bs:
+            yield from flush()
+    yield from flush()
+
+
 def add_noise_to_point_cloud(pts: torch.Tensor, noise_std: float):      # monocular_depth_init.py:90-92
     return pts + torch.randn_like(pts) * noise_std
 
@@ -119,16 +147,40 @@ def pts_and_rgb_from_monocular_depth(config, parser, device: str = "cuda", model
     dataset = type(parser).DatasetCls(parser, split="train")
     use_cache = getattr(config.mdi, "cache_dir", None) is not None
     intrinsic_matrices, proj_matrices, image_sizes = [], [], []
-    for data in dataset:
-        assert data["image"].max() > 1                                  # :122 images are 0-255
+    cache_hits = set()
+
+    def _cached(data):
+        if not use_cache or config.mdi.ignore_cache:
+            return None
+        path = gs_io.depth_cache_path(config.mdi.cache_dir, model.name, dataset_name, data["image_name"])
+        if not path.exists():
+            return None
+        try:
+            depth = gs_io.load_predicted_depth(path, device=device)
+            cache_hits.add(data["image_name"])
+            return depth
+        except Exception as e:  # noqa: BLE001  (reference: any failure -> recompute, :75-80)
+            _LOGGER.warning("Failed to load cached depth for image %s: %s", data["image_name"], e)
+            return None
+
+    def _checked(dataset):
+        for data in dataset:
+            assert data["image"].max() > 1                              # :122 images are 0-255
+            yield data
+
+    for data, predicted_depth in _with_predicted_depths(_checked(dataset), model, device, lambda d: d["image"] / 255.0,
+                                                        lambda d: d["K"], _cached):
         image = InputImage(name=data["image_name"], cam2world=data["camtoworld"], K=data["K"],
                            data=data["image"] / 255.0)
-        intrinsics = CameraIntrinsics(image.K)
-        if use_cache:
-            predicted_depth = predict_depth_or_get_cached_depth(
-                model, image.data, intrinsics, image.name, config, dataset_name, device=device)
-        else:
-            predicted_depth = model.predict_depth(image.data, intrinsics)
+        if use_cache and image.name not in cache_hits:                  # :60-87: a fresh prediction is stored
+            path = gs_io.depth_cache_path(config.mdi.cache_dir, model.name, dataset_name, image.name)
+            if True:
+                path.parent.mkdir(exist_ok=True, parents=True)
+                try:
+                    gs_io.save_predicted_depth(predicted_depth, path)
+                except KeyboardInterrupt:
+                    path.unlink(missing_ok=True)
+                    raise
         assert predicted_depth.depth.device == torch.device(device)     # :140
         try:
             points, subsampling_mask, P, rgbs = get_pts_from_depth(
@@ -172,11 +224,15 @@ def pts_and_rgb_from_frames(config, frames: Iterable[Frame], model, device: str 
     """The loop of pts_and_rgb_from_monocular_depth over in-memory frames, no depth cache."""
     points_list: List[torch.Tensor] = []
     rgbs_list: List[torch.Tensor] = []
-    for data in frames:
-        assert data.image.max() > 1
+    def _checked(frames):
+        for data in frames:
+            assert data.image.max() > 1
+            yield data
+
+    for data, predicted_depth in _with_predicted_depths(_checked(frames), model, device, lambda d: d.image / 255.0,
+                                                        lambda d: d.K):
         image = InputImage(name=data.image_name, cam2world=data.camtoworld, K=data.K,
                            data=data.image / 255.0)
-        predicted_depth = model.predict_depth(image.data, CameraIntrinsics(image.K))
         assert predicted_depth.depth.device == torch.device(device)
         try:
             points, subsampling_mask, P, rgbs = get_pts_from_depth(

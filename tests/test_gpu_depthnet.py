@@ -475,3 +475,45 @@ def test_gru_virtual_concatenation_equals_copied_input(N):
         assert torch.equal(a, b)
     assert torch.equal(d1, d0) and torch.equal(c1, c0) and torch.equal(n1, n0)
     assert torch.equal(d1b, d0) and torch.equal(c1b, c0)
+
+
+@pytest.mark.parametrize("name", ["vits", "vitl"])
+def test_batched_inference_equals_single_images(N, name):
+    """inference({"input": [B,3,H,W]}): the encoder over all B images at once (GEMMs over B * n_tok rows,
+    attention per image), the B decoders as parallel branches of one HIP graph on their own streams and scratch
+    maps. Every image of the batch must come out as it does alone (same kernels; only a GEMM's tile shape may
+    change with the row count, i.e. fp16 rounding), graph replay == eager, and branches must not share state."""
+    cfg = N.CONFIGS[name]
+    sd = _state(cfg, depth_gain=DW.FULL_DEPTH_GAIN)
+    net = N.Metric3DNet(sd, backbone=name, device="cuda", input_size=(112, 168))
+    base = DW.image(112, 168)
+    imgs = torch.cat([base, base.flip(-1), base.flip(-2) * 0.5], 0).contiguous()          # three different images
+    singles = [tuple(t.clone() for t in net.inference({"input": imgs[i:i + 1]})[:2]) + (net.inference({"input": imgs[i:i + 1]})[2]["prediction_normal"].clone(),)
+               for i in range(3)]
+    d, c, o = net.inference({"input": imgs})                      # eager pass + capture + replay
+    d2, c2, o2 = net.inference({"input": imgs})                   # replay again: nothing left behind by the first
+    assert d.shape == (3, 1, 112, 168) and o["prediction_normal"].shape == (3, 4, 112, 168)
+    assert torch.equal(d, d2) and torch.equal(c, c2) and torch.equal(o["prediction_normal"], o2["prediction_normal"])
+    net_e = N.Metric3DNet(sd, backbone=name, device="cuda", input_size=(112, 168), use_graph=False)
+    de, ce, oe = net_e.inference({"input": imgs})
+    assert torch.equal(d, de) and torch.equal(c, ce)
+    for i, (ds, cs, ns) in enumerate(singles):
+        _close(d[i, 0], ds[0, 0].cpu().numpy(), max_frac=2e-3, mean_frac=5e-4, what=f"{name} batch depth {i}")
+        _close(c[i, 0], cs[0, 0].cpu().numpy(), max_frac=5e-3, mean_frac=2e-3, what=f"{name} batch confidence {i}")
+        _close(o["prediction_normal"][i], ns[0].cpu().numpy(), max_frac=5e-3, mean_frac=2e-3, what=f"{name} batch normal {i}")
+    assert float((d[0] - d[1]).abs().max()) > 0.1                 # (the images do differ)
+    # through the predictor: predict_depths == [predict_depth]
+    M = mod("depth_prediction.predictors.metric3d")
+    ifc = mod("depth_prediction.predictors.depth_predictor_interface")
+    net2 = N.Metric3DNet(_state(N.CONFIGS["vits"]), backbone="vits", device="cuda")
+    pred = M.Metric3d(None, "cuda", model=net2, backbone="vits")
+    g = torch.Generator().manual_seed(1)
+    photos = [torch.rand(240, 320, 3, generator=g).cuda(), torch.rand(200, 360, 3, generator=g).cuda(),
+              torch.rand(240, 320, 3, generator=g).cuda()]
+    K = torch.tensor([[300.0, 0, 160], [0, 300.0, 120], [0, 0, 1]])
+    intr = [ifc.CameraIntrinsics(K)] * 3
+    many = pred.predict_depths(photos, intr)
+    for ph, pm in zip(photos, many):
+        one = pred.predict_depth(ph, intr[0])
+        assert pm.depth.shape == ph.shape[:2]
+        assert float((pm.depth - one.depth).abs().max()) <= 2e-3 * float(one.depth.abs().max())

@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backbones", default="vits,vitl")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--batches", default="1,2,4", help="batch sizes of inference() (the init loop's predict_depths uses 4)")
     args = ap.parse_args()
     import torch
 
@@ -54,6 +55,13 @@ def main():
         t_eager = timed(lambda: net.inference({"input": img}))
         net.use_graph = True
         d, c, o = net.inference({"input": img})
+        by_batch = {}
+        for B in [int(b) for b in args.batches.split(",") if int(b) > 1]:
+            imgs = torch.cat([img] * B, 0)
+            net.inference({"input": imgs})                  # eager pass + capture of the B-image graph
+            tB = timed(lambda: net.inference({"input": imgs}))
+            by_batch[str(B)] = {"ms_per_image": tB / B * 1e3, "total_tflops": all_flops * B / tB / 1e12,
+                                "frac_of_fp16_mfma_peak": all_flops * B / tB / 1e12 / MFMA_FP16_PEAK_TFLOPS}
         print(json.dumps({
             "metric": f"Metric3D-{bb} depth network, 616x1064, fp16 MFMA", "backbone": bb,
             "ms_per_image": t_all * 1e3, "images_per_s": 1.0 / t_all,
@@ -61,6 +69,7 @@ def main():
             "encoder_tflop": enc_flops / 1e12, "total_tflop": all_flops / 1e12,
             "encoder_tflops": enc_flops / t_enc / 1e12, "total_tflops": all_flops / t_all / 1e12,
             "frac_of_fp16_mfma_peak": all_flops / t_all / 1e12 / MFMA_FP16_PEAK_TFLOPS,
+            "batched": by_batch,
             "finite": bool(torch.isfinite(d).all() and torch.isfinite(o["prediction_normal"]).all()),
             "weights": "deterministic random (structurally pinned)"}), flush=True)
         del net

@@ -34,8 +34,8 @@ for cam in (0, 0, 25):
     torch.cuda.synchronize()
 b = buf.double().cpu() * 0.01                      # us
 b = b[b[:, 5] > 0]
-names = ["offsets + prefix of real counts", "8-bin count (keys read 1)", "segment starts + keys placed in LDS (keys read 2)",
-         "bitonic segments", "lists written"]
+names = ["keys loaded, prefix of real counts, depth range", "(tile, depth-bin) histogram", "scan + keys placed in LDS by bin",
+         "in-bin ranks + permutation (or networks)", "lists written"]
 d = {n: round(float((b[:, i + 1] - b[:, i]).mean()), 3) for i, n in enumerate(names)}
 d["whole workgroup mean / max"] = [round(float((b[:, 5] - b[:, 0]).mean()), 3), round(float((b[:, 5] - b[:, 0]).max()), 3)]
 d["first start -> last end"] = round(float(b[:, 5].max() - b[:, 0].min()), 3)
