@@ -234,6 +234,260 @@ ssim_bwd_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, Img
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: sliding-window kernels (the launches gsr_ssim_l1_fwd / _bwd now make).
+//
+// The tile kernels above stage a 42 x 42 halo tile and BOTH separable passes through LDS (42 KB per
+// workgroup: three workgroups per CU, three barriers each); at 1080p they took 0.121 + 0.083 ms where the
+// images and maps they move are worth ~0.05 ms of HBM time. Here ONE WAVE owns a strip of 64 columns x
+// SS_ROWS rows of one (image, channel) plane, lane = column, and walks it row by row:
+//   * the row's 74 input values (64 + the 2 x 5 halo) go through a per-wave LDS row buffer -- the only
+//     LDS traffic: 22 (forward) / 33 (backward) conflict-free broadcast-free reads per pixel;
+//   * the horizontally filtered values of the last 11 rows live in REGISTERS (a window per quantity; the
+//     row loop is unrolled by 11 so that every slot index is static), the vertical filter is 11 FMAs per
+//     quantity on registers;
+//   * no workgroup barrier, no shared tile: a wave's LDS operations execute in order, the row buffers are
+//     double buffered, the next row's global loads are issued one row ahead.
+// The 11-tap window is symmetric: taps k and 10 - k share a weight (6 multiplies per 11 taps).
+constexpr int SS_COLS = 64;                        // one column per lane
+#ifndef GSR_SS_ROWS
+#define GSR_SS_ROWS 32
+#endif
+constexpr int SS_ROWS = GSR_SS_ROWS;               // output rows per strip (+ 10 halo rows walked)
+constexpr int SS_W = SS_COLS + 2 * SSIM_R;         // 74 inputs per row
+constexpr int SS_WAVES = 4;                        // strips per 256-thread workgroup (independent)
+
+// Order one lane's LDS stores before the other lanes' loads of the same row (hardware executes a wave's LDS
+// operations in order; this keeps the COMPILER from moving a load of column lane + k above the store of
+// column lane, which alias analysis of a single thread would allow).
+__device__ __forceinline__ void ss_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float sym11(const float v[11]) {     // sum_k G[k] v[k], G symmetric
+  float a = SSIM_G[5] * v[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) a = fmaf(SSIM_G[k], v[k] + v[10 - k], a);
+  return a;
+}
+
+__global__ void __launch_bounds__(64 * SS_WAVES)
+ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
+                   const float *__restrict__ img2, ImgView v2, int valid_only,
+                   double *__restrict__ ws, float *__restrict__ dm_mu1,
+                   float *__restrict__ dm_s1, float *__restrict__ dm_s12) {
+  __shared__ float sRow[SS_WAVES][2][2][SS_W + 2];   // [wave][buffer][image][column]
+  __shared__ double red[2][SS_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles_x = (W + SS_COLS - 1) / SS_COLS, strips = (H + SS_ROWS - 1) / SS_ROWS;
+  const int wid = blockIdx.x * SS_WAVES + wave;
+  const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
+  // per-lane partial sums in fp32 (<= 42 terms of magnitude <= 1 each), fp64 across lanes and workgroups
+  float acc_ssim = 0.f, acc_l1 = 0.f;
+  if (wid < tiles_x * strips) {
+    const int bx = wid % tiles_x, by = wid / tiles_x;
+    const int x0 = bx * SS_COLS, y0 = by * SS_ROWS;
+    const int rows_out = min(SS_ROWS, H - y0);
+    const int gx = x0 + lane;                               // this lane's output column
+    const int gxa = x0 - SSIM_R + lane, gxb = x0 + SS_COLS - SSIM_R + lane;   // columns it stages (b: lanes 0..9)
+    const float *p1 = img1 + n * v1.sn + c * v1.sc, *p2 = img2 + n * v2.sn + c * v2.sc;
+    auto fetch = [&](int j, float &xa, float &ya, float &xb, float &yb) {   // input row j of the strip
+      const int gy = y0 - SSIM_R + j;
+      xa = ya = xb = yb = 0.f;
+      if (gy >= 0 && gy < H) {
+        if (gxa >= 0 && gxa < W) {
+          xa = p1[gy * v1.sh + gxa * v1.sw];
+          ya = p2[gy * v2.sh + gxa * v2.sw];
+        }
+        if (lane < 2 * SSIM_R && gxb < W) {
+          xb = p1[gy * v1.sh + gxb * v1.sw];
+          yb = p2[gy * v2.sh + gxb * v2.sw];
+        }
+      }
+    };
+    float wm1[11], wm2[11], w11[11], w22[11], w12[11];      // horizontally filtered rows: x, y, xx, yy, xy
+    float nxa, nya, nxb, nyb;
+    fetch(0, nxa, nya, nxb, nyb);
+    const int rows_in = rows_out + 2 * SSIM_R;
+    for (int jb = 0; jb < rows_in; jb += 11) {
+#pragma unroll
+      for (int sl = 0; sl < 11; ++sl) {
+        const int j = jb + sl;
+        if (j < rows_in) {                                  // (wave-uniform)
+          float(*buf)[SS_W + 2] = sRow[wave][j & 1];
+          buf[0][lane] = nxa;
+          buf[1][lane] = nya;
+          if (lane < 2 * SSIM_R) {
+            buf[0][SS_COLS + lane] = nxb;
+            buf[1][SS_COLS + lane] = nyb;
+          }
+          ss_wave_sync();
+          if (j + 1 < rows_in) fetch(j + 1, nxa, nya, nxb, nyb);   // in flight during this row's arithmetic
+          float xs[11], ys[11], t[11];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            xs[k] = buf[0][lane + k];
+            ys[k] = buf[1][lane + k];
+          }
+          // the L1 term of this row's own pixel (input row j is output row j - 5; the lane's column is tap 5)
+          if (j >= SSIM_R && j < rows_out + SSIM_R && gx < W) acc_l1 += fabsf(xs[SSIM_R] - ys[SSIM_R]);
+          wm1[sl] = sym11(xs);
+          wm2[sl] = sym11(ys);
+#pragma unroll
+          for (int k = 0; k < 11; ++k) t[k] = xs[k] * xs[k];
+          w11[sl] = sym11(t);
+#pragma unroll
+          for (int k = 0; k < 11; ++k) t[k] = ys[k] * ys[k];
+          w22[sl] = sym11(t);
+#pragma unroll
+          for (int k = 0; k < 11; ++k) t[k] = xs[k] * ys[k];
+          w12[sl] = sym11(t);
+          if (j >= 2 * SSIM_R) {                            // output row i = j - 10: window rows j-10 .. j
+            const int i = j - 2 * SSIM_R, gy = y0 + i;
+            float o1[11], o2[11], o11[11], o22[11], o12[11];
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {                  // slot of input row (j - 10 + k)
+              const int q = (sl + 1 + k) % 11;
+              o1[k] = wm1[q];
+              o2[k] = wm2[q];
+              o11[k] = w11[q];
+              o22[k] = w22[q];
+              o12[k] = w12[q];
+            }
+            const float mu1 = sym11(o1), mu2 = sym11(o2), e11 = sym11(o11), e22 = sym11(o22), e12 = sym11(o12);
+            if (gx < W) {
+              const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+              const float A = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B = s1 + s2 + SSIM_C2;
+              const float Cc = 2.f * mu1 * mu2 + SSIM_C1, D = 2.f * s12 + SSIM_C2;
+              const float iAB = 1.0f / (A * B);
+              const float m = Cc * D * iAB;
+              const bool counted = !valid_only || (gx >= SSIM_R && gx < W - SSIM_R && gy >= SSIM_R && gy < H - SSIM_R);
+              if (counted) acc_ssim += m;
+              if (dm_mu1) {
+                const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+                const float w = counted ? 1.f : 0.f;   // cropped pixels get no gradient
+                dm_mu1[o] = w * (2.f * mu2 * D * iAB - 2.f * mu2 * Cc * iAB - 2.f * mu1 * Cc * D * iAB / A +
+                                 2.f * mu1 * Cc * D * iAB / B);
+                dm_s1[o] = w * (-Cc * D * iAB / B);
+                dm_s12[o] = w * (2.f * Cc * iAB);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  const double w_ssim = wave_sum_f64((double)acc_ssim), w_l1 = wave_sum_f64((double)acc_l1);
+  if (lane == 0) {
+    red[0][wave] = w_ssim;
+    red[1][wave] = w_l1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {      // one pair of partial sums per workgroup, plain stores (see ssim_fwd_kernel)
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < SS_WAVES; ++w) {
+      a += red[0][w];
+      b += red[1][w];
+    }
+    ws[2 * wg + 0] = a;
+    ws[2 * wg + 1] = b;
+  }
+}
+
+__global__ void __launch_bounds__(64 * SS_WAVES)
+ssim_bwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, ImgView v1,
+                   const float *__restrict__ img2, ImgView v2, const float *__restrict__ dm_mu1,
+                   const float *__restrict__ dm_s1, const float *__restrict__ dm_s12,
+                   const float *__restrict__ weights, const float *__restrict__ upstream,
+                   float scale_ssim, float scale_l1, float *__restrict__ grad, ImgView vg) {
+  __shared__ float sRow[SS_WAVES][2][3][SS_W + 2];   // [wave][buffer][map][column]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles_x = (W + SS_COLS - 1) / SS_COLS, strips = (H + SS_ROWS - 1) / SS_ROWS;
+  const int wid = blockIdx.x * SS_WAVES + wave;
+  if (wid >= tiles_x * strips) return;
+  const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
+  const int bx = wid % tiles_x, by = wid / tiles_x;
+  const int x0 = bx * SS_COLS, y0 = by * SS_ROWS;
+  const int rows_out = min(SS_ROWS, H - y0);
+  const int gx = x0 + lane;
+  const int gxa = x0 - SSIM_R + lane, gxb = x0 + SS_COLS - SSIM_R + lane;
+  const float up = upstream ? upstream[0] : 1.0f;
+  const float w_ssim = weights ? weights[0] : up * scale_ssim;
+  const float w_l1 = weights ? weights[1] : up * scale_l1;
+  const int64_t pbase = (int64_t)plane * H * W;
+  auto fetch = [&](int j, float a[2], float b[2], float d[2]) {
+    const int gy = y0 - SSIM_R + j;
+    a[0] = a[1] = b[0] = b[1] = d[0] = d[1] = 0.f;
+    if (gy >= 0 && gy < H) {
+      const int64_t ro = pbase + (int64_t)gy * W;
+      if (gxa >= 0 && gxa < W) {
+        a[0] = dm_mu1[ro + gxa];
+        b[0] = dm_s1[ro + gxa];
+        d[0] = dm_s12[ro + gxa];
+      }
+      if (lane < 2 * SSIM_R && gxb < W) {
+        a[1] = dm_mu1[ro + gxb];
+        b[1] = dm_s1[ro + gxb];
+        d[1] = dm_s12[ro + gxb];
+      }
+    }
+  };
+  float wa[11], wb[11], wd[11];
+  float na[2], nb[2], nd[2];
+  fetch(0, na, nb, nd);
+  const int rows_in = rows_out + 2 * SSIM_R;
+  for (int jb = 0; jb < rows_in; jb += 11) {
+#pragma unroll
+    for (int sl = 0; sl < 11; ++sl) {
+      const int j = jb + sl;
+      if (j < rows_in) {
+        float(*buf)[SS_W + 2] = sRow[wave][j & 1];
+        buf[0][lane] = na[0];
+        buf[1][lane] = nb[0];
+        buf[2][lane] = nd[0];
+        if (lane < 2 * SSIM_R) {
+          buf[0][SS_COLS + lane] = na[1];
+          buf[1][SS_COLS + lane] = nb[1];
+          buf[2][SS_COLS + lane] = nd[1];
+        }
+        ss_wave_sync();
+        if (j + 1 < rows_in) fetch(j + 1, na, nb, nd);
+        float t[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) t[k] = buf[0][lane + k];
+        wa[sl] = sym11(t);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) t[k] = buf[1][lane + k];
+        wb[sl] = sym11(t);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) t[k] = buf[2][lane + k];
+        wd[sl] = sym11(t);
+        if (j >= 2 * SSIM_R) {
+          const int gy = y0 + j - 2 * SSIM_R;
+          float oa[11], ob[11], od[11];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            const int q = (sl + 1 + k) % 11;
+            oa[k] = wa[q];
+            ob[k] = wb[q];
+            od[k] = wd[q];
+          }
+          const float a = sym11(oa), b = sym11(ob), d = sym11(od);
+          if (gx < W) {
+            const float x = img1[n * v1.sn + c * v1.sc + gy * v1.sh + gx * v1.sw];
+            const float y = img2[n * v2.sn + c * v2.sc + gy * v2.sh + gx * v2.sw];
+            const float df = x - y;
+            const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+            grad[n * vg.sn + c * vg.sc + gy * vg.sh + gx * vg.sw] = w_l1 * sgn + w_ssim * (a + 2.f * x * b + y * d);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Plain L1 (runner.py:506 with ssim_lambda = 0): contiguous buffers, 16 B per lane.
 __global__ void __launch_bounds__(256)
 l1_fwd_kernel(int64_t n, const float *__restrict__ a, const float *__restrict__ b,
@@ -366,9 +620,16 @@ extern "C" int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1,
   const double n_l1 = (double)N * CH * H * W;
   gsr::ImgView v1{strides1[0], strides1[1], strides1[2], strides1[3]};
   gsr::ImgView v2{strides2[0], strides2[1], strides2[2], strides2[3]};
+#ifdef GSR_SSIM_TILE_KERNELS
   dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
   hipLaunchKernelGGL(gsr::ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
                      img1, v1, img2, v2, valid_only, workspace, dm_mu1, dm_s1, dm_s12);
+#else
+  // (a strip of 64 x 32 pixels per wave: never more partial sums than the 32 x 32 tiles the workspace is sized for)
+  dim3 grid(gsr::ceil_div(gsr::ceil_div(W, gsr::SS_COLS) * gsr::ceil_div(H, gsr::SS_ROWS), gsr::SS_WAVES), N * CH);
+  hipLaunchKernelGGL(gsr::ssim_fwd_sw_kernel, grid, dim3(64 * gsr::SS_WAVES), 0, (hipStream_t)stream, N, CH, H, W,
+                     img1, v1, img2, v2, valid_only, workspace, dm_mu1, dm_s1, dm_s12);
+#endif
   GSR_CHECK_LAUNCH("ssim_l1_fwd");
   hipLaunchKernelGGL(gsr::ssim_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
                      (int)(grid.x * grid.y), workspace, out, 1.0 / (n_ssim > 0 ? n_ssim : 1.0),
@@ -394,10 +655,17 @@ extern "C" int gsr_ssim_l1_bwd(int N, int CH, int H, int W, const float *img1,
   gsr::ImgView v1{strides1[0], strides1[1], strides1[2], strides1[3]};
   gsr::ImgView v2{strides2[0], strides2[1], strides2[2], strides2[3]};
   gsr::ImgView vg{stridesg[0], stridesg[1], stridesg[2], stridesg[3]};
+#ifdef GSR_SSIM_TILE_KERNELS
   dim3 grid(gsr::ceil_div(W, gsr::SSIM_T) * gsr::ceil_div(H, gsr::SSIM_T), N * CH);
   hipLaunchKernelGGL(gsr::ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
                      img1, v1, img2, v2, dm_mu1, dm_s1, dm_s12, weights, upstream, scale_ssim,
                      scale_l1, grad, vg);
+#else
+  dim3 grid(gsr::ceil_div(gsr::ceil_div(W, gsr::SS_COLS) * gsr::ceil_div(H, gsr::SS_ROWS), gsr::SS_WAVES), N * CH);
+  hipLaunchKernelGGL(gsr::ssim_bwd_sw_kernel, grid, dim3(64 * gsr::SS_WAVES), 0, (hipStream_t)stream, N, CH, H, W,
+                     img1, v1, img2, v2, dm_mu1, dm_s1, dm_s12, weights, upstream, scale_ssim,
+                     scale_l1, grad, vg);
+#endif
   GSR_CHECK_LAUNCH("ssim_l1_bwd");
   return GSR_OK;
 }
