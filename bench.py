@@ -460,6 +460,23 @@ def main():
                           "ubench_source": "profiles/r03_valu_rate_long.jsonl",
                           "frac_of_plain_valu_rate": (plain / cpi) if plain else None}
 
+    # The largest HBM-bound kernel of the step, beside the (issue-bound) dominant one: the projection backward with
+    # the Adam update fused in. Algorithmic bytes per Gaussian: the 59 parameters and their two moments read and
+    # written (59 * 4 * 6 = 1416), the 36 used bytes of its gradient row, radii 8, activated opacity 4.
+    hbm_kernel = None
+    pb = times.get("gsr_project_bwd_adam")
+    if pb is not None and pb[1] == pb[1] and pb[1] > 0 and world == 1 and not args.no_optimizer and not args.separate_adam:
+        pb_bytes = N * (59 * 4 * 6 + 36 + 8 + 4)
+        pb_traffic = None
+        if pmc.exists():
+            kc2 = json.loads(pmc.read_text()).get("kernels", {}).get("gsr_project_bwd_adam", {})
+            if "FETCH_SIZE" in kc2 and "WRITE_SIZE" in kc2:
+                pb_traffic = int((2 * kc2["FETCH_SIZE"] + kc2["WRITE_SIZE"]) * 1024)
+        hbm_kernel = {"bound": "hbm", "kernel": "project_bwd_adam1_kernel (gsr_project_bwd_adam, one camera)",
+                      "achieved": pb_bytes / (pb[1] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": pb_bytes / (pb[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pb_traffic,
+                      "algorithmic_bytes_per_launch": pb_bytes, "avg_launch_ms": pb[1]}
+
     if rank == 0:
         line = {
             "metric": "train iters/sec (fwd+bwd rasterize) @1M Gaussians, 1080p; 1/2/4/8 GPU",
@@ -488,6 +505,7 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                 "valu_issue": valu_issue, "counters_from": pmc_src,
             },
+            "roofline_largest_hbm_bound_kernel": hbm_kernel,
             "metric_8d_fwd_bwd_grads_materialised": metric_8d,
             "metric_full_loss_step": metric_full,
             "sync_modes": sync_modes, "collectives": collectives,

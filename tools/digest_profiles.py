@@ -40,11 +40,12 @@ traffic = {}
 # keyed on the FULL templated kernel name: project_bwd_kernel<true> (Adam fused in: the headline step's kernel)
 # and <false> (gradients written) are different kernels with different traffic; first match wins
 names = [("raster_bwd_kernel", "gsr_rasterize_bwd"), ("raster_fwd_kernel", "gsr_rasterize_fwd"),
-         ("project_fwd_kernel", "gsr_project_fwd"), ("project_bwd_kernel<true>", "gsr_project_bwd_adam"),
+         ("project_fwd_kernel", "gsr_project_fwd"), ("project_bwd_adam1_kernel", "gsr_project_bwd_adam"),
+         ("project_bwd_kernel<true>", "gsr_project_bwd_adam_generic"),
          ("project_bwd_kernel<false>", "gsr_project_bwd"), ("bucket_count_kernel", "gsr_bucket_count"),
          ("bucket_emit_kernel", "gsr_bucket_emit"), ("bucket_sort_kernel", "gsr_bucket_sort"),
          ("tile_order_kernel", "gsr_tile_order"), ("l1_fwd_kernel", "gsr_l1_fwd"),
-         ("ssim_fwd_kernel", "gsr_ssim_fwd"), ("ssim_bwd_kernel", "gsr_ssim_bwd"),
+         ("ssim_fwd", "gsr_ssim_fwd"), ("ssim_bwd", "gsr_ssim_bwd"),
          ("isect_emit_kernel", "gsr_isect_emit"), ("tile_sort_small_kernel", "gsr_tile_sort"),
          ("adam_kernel", "gsr_adam_step")]
 
