@@ -517,10 +517,17 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 //   * the registers that frees hold the Adam moments of the 14 short-row parameters, requested BEFORE the
 //     SH passes so that they arrive under ~400 VALU instructions, and the parameters themselves are
 //     reused from the loads at the top instead of being read again.
+#ifndef GSR_PBWD1_KEEP_P
+#define GSR_PBWD1_KEEP_P 0
+#endif
 #ifndef GSR_PBWD1_WAVES
 #define GSR_PBWD1_WAVES 4   // waves per workgroup of the single-camera kernel (no workgroup-level synchronisation in it)
 #endif
+#ifdef GSR_PBWD1_MIN_BLOCKS
+__global__ void __launch_bounds__(64 * GSR_PBWD1_WAVES, GSR_PBWD1_MIN_BLOCKS)
+#else
 __global__ void __launch_bounds__(64 * GSR_PBWD1_WAVES)
+#endif
 project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *__restrict__ K,
                          const float *__restrict__ campos, int width, int height, float eps2d,
                          int sh_degree, const int32_t *__restrict__ radii,
@@ -608,6 +615,17 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
     v_m[10] = af.v[AF_OPAC][i];
   }
   float *cn = slab + lane * 45;      // this lane's row: coefficients in, gradients out
+#if GSR_PBWD1_KEEP_P
+  // The shN parameters in the LINEAR order of the Adam phase, taken from the slab before pass 2 turns it into
+  // gradients: without them the Adam phase reads the 180 bytes per Gaussian a second time from global memory
+  // (0.18 GB of the kernel's 0.96 GB of fetches, profiles/r04b_pmc.json).
+  float4 p_lin[12];
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int idx = it * 64 + lane;
+    p_lin[it] = (idx < 64 * 45 / 4) ? reinterpret_cast<const float4 *>(slab)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#endif
   if (visible) {
     // pass 1: pre-clamp colour, for the clamp_min(., 0) mask
     float col[3] = {0.f, 0.f, 0.f};
@@ -688,14 +706,23 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
     const float4 *G4 = reinterpret_cast<const float4 *>(slab);
     const float ss = af.step_size[AF_SHN], bc2 = af.bc2_sqrt[AF_SHN];
     __builtin_amdgcn_wave_barrier();
+#if GSR_PBWD1_KEEP_P
+#pragma unroll
+#else
 #pragma unroll GSR_ADAM_UNROLL
+#endif
     for (int it = 0; it < 12; ++it) {
       const int idx = it * 64 + lane;
       if (idx < 64 * 45 / 4) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v mmv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&M4[idx]));
         const f4v vvv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&V4[idx]));
-        float4 pp = P4[idx], mm = make_float4(mmv.x, mmv.y, mmv.z, mmv.w), vv = make_float4(vvv.x, vvv.y, vvv.z, vvv.w);
+#if GSR_PBWD1_KEEP_P
+        float4 pp = p_lin[it];
+#else
+        float4 pp = P4[idx];
+#endif
+        float4 mm = make_float4(mmv.x, mmv.y, mmv.z, mmv.w), vv = make_float4(vvv.x, vvv.y, vvv.z, vvv.w);
         const float4 gg = G4[idx];
         adam_one(pp.x, gg.x, mm.x, vv.x, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
         adam_one(pp.y, gg.y, mm.y, vv.y, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);

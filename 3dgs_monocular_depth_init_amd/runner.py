@@ -395,7 +395,7 @@ def train(
         if len(order) < need:                       # DataLoader(shuffle=True): a fresh permutation per epoch
             order = order + torch.randperm(n_train, generator=gen).tolist()
         take, order = order[:need], order[need:]
-        return [trainset[i] for i in take[world_rank::W]]
+        return [trainset[i] for i in take[world_rank::W]], take
 
     save_at = {i - 1 for i in cfg.save_steps} | {max_steps - 1}
     eval_at = {i - 1 for i in cfg.eval_steps}
@@ -407,7 +407,14 @@ def train(
     tic, tic_step = time.perf_counter(), 0
     try:
         for step in range(max_steps):
-            data = next_batch()
+            data, everyone = next_batch()
+            if grad_sync is not None and hasattr(grad_sync, "set_views"):
+                # distributed.GatherRowsSync: every rank runs the projection backward over the cameras of ALL
+                # ranks (row r = the camera rank r renders in this step)
+                if B != 1:
+                    raise ValueError("the row exchange renders one view per rank per step (cfg.batch_size = 1)")
+                grad_sync.set_views(torch.stack([trainset[i]["camtoworld"].to(device) for i in everyone]),
+                                    torch.stack([trainset[i]["K"].to(device) for i in everyone]))
             c2w = torch.stack([d["camtoworld"].to(device) for d in data])
             Ks = torch.stack([d["K"].to(device) for d in data])
             pixels = torch.stack([d["image"].to(device) for d in data]).float() / 255.0

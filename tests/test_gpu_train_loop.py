@@ -127,3 +127,113 @@ def test_train_step_random_background_and_depth_loss():
         assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in gg.values())
     assert l1 != l0 and float((g1["opacities"] - g0["opacities"]).abs().max()) > 0
     assert l2 > l0 and float((g2["means"] - g0["means"]).abs().max()) > 0
+
+
+def test_train_loop_mcmc_preset():
+    """The "mcmc" preset (trainer.py:83-92: MCMCStrategy, opacity_reg = scale_reg = 0.01, init_opa 0.5,
+    init_scale 0.1) through runner.train: every step is a strategy step (position noise reads the pre-update
+    parameters), so the optimizer never fuses into the backward; relocation and growth to cap_max happen on the
+    scaled schedule, the loss falls."""
+    runner = importlib.import_module(P + "runner")
+    cfgm = importlib.import_module(P + "config")
+    S = importlib.import_module(P + "strategy")
+    knn = importlib.import_module(P + "knn")
+    torch.manual_seed(0)
+    W, H = 160, 112
+    gt, frames = _dataset(W, H, n_gt=2000, n_views=10)
+    n0 = 1000
+    cfg = cfgm.Config(strategy=S.MCMCStrategy(cap_max=1600), opacity_reg=0.01, scale_reg=0.01, init_opa=0.5, init_scale=0.1)
+    cfg.adjust_steps(0.02)                                  # 600 steps: refine 10 -> 500 every 2
+    assert (cfg.max_steps, cfg.strategy.refine_start_iter, cfg.strategy.refine_stop_iter, cfg.strategy.refine_every) == (600, 10, 500, 2)
+    cfg.save_steps, cfg.eval_steps = [], []
+    pts = gt["means"][:n0] + 0.02 * torch.randn(n0, 3)
+    splats, opts = runner.create_splats_with_optimizers(pts, torch.rand(n0, 3), knn.initial_log_scales(pts.cuda(), cfg.init_scale).cpu(),
+                                                        init_opacity=cfg.init_opa)
+    stats = runner.train(splats, opts, frames, cfg, progress_every=100)
+    losses = [r["loss"] for r in stats["intervals"]]
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < 0.8 * losses[0], losses
+    assert n0 < stats["num_GS"] <= 1600, stats["num_GS"]
+    assert stats["final_lr_means"] == pytest.approx(0.01 * 1.6e-4, rel=1e-6)
+    for k, p in splats.items():
+        assert opts[k].state[p]["exp_avg"].shape == p.shape
+
+
+def _train_worker(rank, world, port, q, mode):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        runner = importlib.import_module(P + "runner")
+        cfgm = importlib.import_module(P + "config")
+        D = importlib.import_module(P + "distributed")
+        R = importlib.import_module(P + "rendering")
+        knn = importlib.import_module(P + "knn")
+        torch.manual_seed(0)
+        W, H = 96, 64
+        gt, frames = _dataset(W, H, n_gt=1500, n_views=8)
+        n0 = 900
+        pts = gt["means"][:n0] + 0.02 * torch.randn(n0, 3, generator=torch.Generator().manual_seed(1))
+        splats, opts = runner.create_splats_with_optimizers(
+            pts, torch.rand(n0, 3, generator=torch.Generator().manual_seed(2)), knn.initial_log_scales(pts.cuda()).cpu(),
+            init_opacity=0.3, world_size=world)
+        cfg = cfgm.Config()
+        cfg.adjust_steps(0.004)                              # 120 steps; refine 2 -> 60 every step... keep it gentle:
+        cfg.strategy.refine_every, cfg.strategy.refine_start_iter, cfg.strategy.reset_every = 20, 20, 1000
+        cfg.strategy.grow_grad2d = 1e-4
+        cfg.save_steps, cfg.eval_steps = [], []
+        if mode == "gather":
+            fused = D.fuse_optimizers(splats, opts)
+            sync = D.GatherRowsSync(fused, world, rank, chunks=2, min_chunk=256)
+            try:
+                stats = runner.train(splats, fused, frames, cfg, grad_sync=sync, world_rank=rank, world_size=world, progress_every=40)
+            finally:
+                sync.close()
+        else:
+            sync = D.GradSync(splats, world, chunks=2)
+            try:
+                stats = runner.train(splats, opts, frames, cfg, grad_sync=sync, world_rank=rank, world_size=world, progress_every=40)
+            finally:
+                R.set_grad_arena(None)
+        torch.cuda.synchronize()
+        q.put((rank, {k: p.detach().cpu().numpy() for k, p in splats.items()}, [r["loss"] for r in stats["intervals"]], "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["gather", "allreduce"])
+def test_train_loop_two_ranks_replicas_stay_identical(mode):
+    """runner.train on two REAL ranks sharing the test box's one GPU (gloo moving CUDA tensors): view-parallel
+    replicas, rank r renders entry r of every shuffled batch of 2, gradients exchanged by the all-gather of
+    view-space rows (`GatherRowsSync`; train() hands it all ranks' cameras every step) or the all-reduce of the
+    parameter gradients (`GradSync`), densification with all-reduced statistics and a shared seed. After 120
+    steps incl. refinement the replicas hold bit-identical parameters of identical size."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        rank, params, losses, msg = q.get(timeout=300)
+        assert msg == "ok", msg
+        res[rank] = (params, losses)
+    for p in procs:
+        p.join(60)
+    (p0, l0), (p1, l1) = res[0], res[1]
+    for k in p0:
+        assert p0[k].shape == p1[k].shape, k
+        assert (p0[k] == p1[k]).all(), k
+    assert p0["means"].shape[0] != 900            # densification changed the count, identically on both
+    assert all(math.isfinite(x) for x in l0 + l1)
