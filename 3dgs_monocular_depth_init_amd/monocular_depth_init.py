@@ -174,13 +174,12 @@ def pts_and_rgb_from_monocular_depth(config, parser, device: str = "cuda", model
                            data=data["image"] / 255.0)
         if use_cache and image.name not in cache_hits:                  # :60-87: a fresh prediction is stored
             path = gs_io.depth_cache_path(config.mdi.cache_dir, model.name, dataset_name, image.name)
-            if True:
-                path.parent.mkdir(exist_ok=True, parents=True)
-                try:
-                    gs_io.save_predicted_depth(predicted_depth, path)
-                except KeyboardInterrupt:
-                    path.unlink(missing_ok=True)
-                    raise
+            path.parent.mkdir(exist_ok=True, parents=True)
+            try:
+                gs_io.save_predicted_depth(predicted_depth, path)
+            except KeyboardInterrupt:
+                path.unlink(missing_ok=True)
+                raise
         assert predicted_depth.depth.device == torch.device(device)     # :140
         try:
             points, subsampling_mask, P, rgbs = get_pts_from_depth(

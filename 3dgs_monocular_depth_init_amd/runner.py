@@ -471,5 +471,4 @@ def train(
     stats["final_lr_means"] = means_opt.param_groups[0]["lr"]
     stats["num_GS"] = len(splats["means"])
     stats["peak_mem_gib"] = torch.cuda.max_memory_allocated() / 1024 ** 3
-    stats["strategy_state"] = None
     return stats

@@ -36,7 +36,6 @@ ap.add_argument("--views", type=int, default=100)
 ap.add_argument("--result-dir", default="/tmp/c5_rehearsal")      # (checkpoints of a few GB: not under gpurun_out)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
-ap.add_argument("--max-minutes", type=float, default=14.0, help="progress lines only; the run itself is bounded by max_steps")
 args = ap.parse_args()
 P = "3dgs_monocular_depth_init_amd."
 runner = importlib.import_module(P + "runner")
