@@ -160,7 +160,11 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
         }
         if (f == GSR_GR_OPAC) val = -val / rec[1][j].y;   // row holds sum v_sigma
         if (f == GSR_GR_CONIC || f == GSR_GR_CONIC + 2) val *= 0.5f;
+#if defined(GSR_BWD_KO) && GSR_BWD_KO == 3   // knock-out (timing only): no atomics
+        if (val == 1.2345e-30f) grad_rows[(int64_t)g * GSR_GRAD_ROW + f] = val;
+#else
         atomicAdd(grad_rows + (int64_t)g * GSR_GRAD_ROW + f, val);
+#endif
       }
     }
   };
@@ -244,7 +248,11 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
          if (qm & (1u << q)) {   // scalar branch
           const float dx = Ac.x - px[h];
           const float sg = sigma_l2(Ac.z, dx, Br, Cr);
+#if defined(GSR_BWD_KO) && GSR_BWD_KO == 2   // knock-out (timing only): no transcendental
+          const float vis = 1.0f - 0.001f * sg;
+#else
           const float vis = __builtin_amdgcn_exp2f(-sg);
+#endif
           const float ov = opac * vis;
           // valid <=> sigma >= 0 and alpha = min(0.999, ov) >= 1/255 (<=> ov >= 1/255):
           // sigma's sign bit is OR-ed into ov, so one compare covers both
@@ -256,7 +264,11 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
           const float ovv = valid ? ov : 0.f;
           // FAST: opacity <= 0.999 and exp2(-sigma) <= 1, so the clamp cannot bind
           const float a = FAST ? ovv : fminf(gs::ALPHA_MAX, ovv);
+#if defined(GSR_BWD_KO) && GSR_BWD_KO == 2
+          const float ra = 1.0f + a;
+#else
           const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+#endif
           T[q] *= ra;
           const float fac = a * T[q];
           float D = col[0] * vout[q][0];      // <colour, v_out>
@@ -306,8 +318,13 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
       {
         const float tv[8] = {g_xy[0], g_xy[1], g_con[0], g_con[1], g_con[2], g_col[0],
                              (CH > 1) ? g_col[1] : 0.f, (CH > 2) ? g_col[2] : 0.f};
+#if defined(GSR_BWD_KO) && GSR_BWD_KO == 1   // knock-out (timing only): no cross-lane reduction
+        float u = tv[0] + tv[1] + tv[2] + tv[3] + tv[4] + tv[5] + tv[6] + tv[7];
+        const float r_s = g_vs;
+#else
         float u = tree_reduce8(tv, lane);
         const float r_s = wave_sum_xlane(g_vs, lane);
+#endif
         u = (lane == 63) ? r_s : u;
         u = (lane == 1) ? 1.0f : u;
         float *row = &sG[j][0];
@@ -386,6 +403,16 @@ static int launch_bwd(int n_tiles, const float *records, const float *background
                       const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *grad_rows, hipStream_t stream) {
   const unsigned pad = (unsigned)gsr_knob_int("GSR_BWD_LDS_PAD", 0);   // experiment knob: see raster_fwd.hip (0 in the product build)
+  // experiment knob (timing only, wrong gradients): launch just the GSR_BWD_TILE_LIMIT longest tiles, or (negative)
+  // skip the -limit longest -- how much of the launch is the under-occupied tail of its 8160 / 6144-slot schedule?
+  {
+    const int lim = gsr_knob_int("GSR_BWD_TILE_LIMIT", 0);
+    if (lim > 0 && lim < n_tiles) n_tiles = lim;
+    if (lim < 0 && -lim < n_tiles && tile_order) {
+      tile_order += -lim;
+      n_tiles -= -lim;
+    }
+  }
   if (absgrad)
     hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), pad, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
