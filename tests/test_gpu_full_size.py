@@ -190,7 +190,8 @@ def test_c5_ranges_sorted_lists_and_linearity(R):
         assert rel < 1e-4, f"{k}: {rel:.2e}"
 
 
-def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_path=False):
+def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_path=False, render_mode="RGB",
+                  antialiased=False, img_atol=1e-4):
     """Oracle (CPU, ONE run) against the HIP path on camera 25's window of the 1080p frame.
 
     default path: `rendering.rasterization` with gsplat's rectangle-rule lists and activated inputs.
@@ -219,7 +220,8 @@ def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_pat
     act["scales"].retain_grad()
     act["opacities"].retain_grad()
     out_c = O.rasterization(act["means"], act["quats"], act["scales"], act["opacities"],
-                            torch.cat([act["sh0"], act["shN"]], 1), vm, K, width, height, sh_degree=sh_degree)
+                            torch.cat([act["sh0"], act["shN"]], 1), vm, K, width, height, sh_degree=sh_degree,
+                            render_mode=render_mode, rasterize_mode="antialiased" if antialiased else "classic")
     g = torch.Generator().manual_seed(11)
     w_c, w_a = torch.randn(out_c[0].shape, generator=g), torch.randn(out_c[1].shape, generator=g)
     ((out_c[0] * w_c).sum() + (out_c[1] * w_a).sum()).backward()
@@ -240,15 +242,16 @@ def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_pat
     gpu = {k: act[k].detach().clone().cuda().requires_grad_(True) for k in names}
     out_g = hip(lambda: Rm.rasterization(gpu["means"], gpu["quats"], gpu["scales"], gpu["opacities"],
                                          (gpu["sh0"], gpu["shN"]), vm.cuda(), K.cuda(), width, height,
-                                         sh_degree=sh_degree, packed=False))
-    _check(act, gpu, out_c, out_g, mean_frac=5e-2, flip_frac=2e-4)
+                                         sh_degree=sh_degree, packed=False, render_mode=render_mode,
+                                         rasterize_mode="antialiased" if antialiased else "classic"))
+    _check(act, gpu, out_c, out_g, mean_frac=5e-2, flip_frac=2e-4, img_atol=img_atol)
     if timed_path:
         # (b) the timed configuration: raw parameters, tight lists, through runner.rasterize_splats
         gpu_raw = torch.nn.ParameterDict({k: torch.nn.Parameter(raw[k].clone().cuda()) for k in names})
-        cfg = runner.RasterConfig(sh_degree=3, tight_tiles=True)
+        cfg = runner.RasterConfig(sh_degree=3, tight_tiles=True, antialiased=antialiased)
         out_r = hip(lambda: runner.rasterize_splats(gpu_raw, torch.linalg.inv(vm).cuda(), K.cuda(), width, height,
-                                                    cfg, sh_degree=sh_degree))
-        _check(cpu_raw, gpu_raw, out_c, out_r, mean_frac=5e-2, flip_frac=2e-4)
+                                                    cfg, sh_degree=sh_degree, render_mode=render_mode))
+        _check(cpu_raw, gpu_raw, out_c, out_r, mean_frac=5e-2, flip_frac=2e-4, img_atol=img_atol)
     print(f"{n_gauss} Gaussians, view {width}x{height}, SH degree {sh_degree}: oracle fwd+bwd {t_oracle:.1f} s, "
           f"total {time.perf_counter() - t0:.1f} s")
 
@@ -267,6 +270,16 @@ def test_c2_window_vs_oracle_lower_sh_degrees(sh_degree):
     and 2 read shN band-wise (a different code path from degree 3's LDS-DMA slab), degree 0 reads sh0 only;
     the unused bands must receive exactly zero gradient. Both paths, as above."""
     _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0, sh_degree=sh_degree, timed_path=True)
+
+
+def test_c2_window_depth_channel_antialiased_vs_oracle():
+    """The other two modes the reference's callers use, at c2 scale: render_mode "RGB+ED" (the depth-loss branch
+    runner.py:476-482 and the nerfbaselines render, method.py:754-764: expected depth as a fourth channel, divided
+    by alpha) with rasterize_mode "antialiased" (config.py:149: the compensation factor multiplies the opacity, the
+    sigmoid chain rule then runs outside the projection kernel). Both paths; the depth channel's magnitude is ~4,
+    hence the absolute tolerance 5e-4 (as in the tiny-scene test of the same mode)."""
+    _c2_vs_oracle(512, 512, 960.0 - 704.0, 540.0 - 284.0, timed_path=True, render_mode="RGB+ED", antialiased=True,
+                  img_atol=5e-4)
 
 
 def test_c5_window_vs_oracle():
