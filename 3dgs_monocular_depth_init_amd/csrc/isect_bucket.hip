@@ -656,12 +656,14 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   NB = max(1, min(NB, BK_MAX_BINS / BK_TILES));
   const float fmin = __uint_as_float(dmin_s), fmax = __uint_as_float(dmax_s);   // depths are positive floats
   const float span = fmax - fmin;
-  const float bscale = span > 0.f ? (float)NB / span : 0.f;
+  // (a span too small for NB / span to be finite -- equal or nearly equal depths -- means one bin per tile)
+  const float bscale = (span > 1e-30f && span < 3.0e38f) ? (float)NB / span : 0.f;
   // monotone in the depth bits: float subtraction and multiplication by a positive constant round
-  // monotonically, truncation is monotone, the clamp keeps the top edge inside
+  // monotonically, truncation is monotone, the clamps keep both edges inside (and send a NaN, which no
+  // finite depth produces here, to bin 0 instead of an out-of-range index)
   auto bin_of = [&](uint64_t k) {
-    const float d = __uint_as_float(depth_of(k));
-    const int db = min(NB - 1, (int)((d - fmin) * bscale));
+    const float t = (__uint_as_float(depth_of(k)) - fmin) * bscale;
+    const int db = t >= 0.f ? (t < (float)NB ? (int)t : NB - 1) : 0;
     return (int)(k >> 61) * NB + db;
   };
   const int nbins = BK_TILES * NB;

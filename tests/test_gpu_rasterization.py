@@ -145,6 +145,43 @@ def test_tiny_sh_degrees(R, sh_degree):
     _check(*_run_both(R, sc, vm, K, W, H, sh_degree=sh_degree))
 
 
+@pytest.mark.parametrize("tight", [False, True])
+def test_equal_depths_keep_index_order(R, tight):
+    """Every Gaussian on one plane facing the camera: all depths are the SAME float, so every tile's list is one
+    long tie that the sort key's index bits must order (gsplat: stable sort by (tile, depth), values in index
+    order). With the depth-bin split of round 4 such a bucket has ONE bin per tile, far longer than the in-bin
+    rank handles, and takes the bitonic networks kept for it: lists bit-exact against the oracle's stable sort,
+    image and gradients as usual."""
+    N = 4000
+    g = torch.Generator().manual_seed(31)
+    sc = scenes.make_scene(N, 31, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    sc["means"][:, 2] = 0.25                      # one plane; the camera below looks along +z from z = -2.5
+    vm = torch.eye(4)[None].clone()
+    vm[0, 2, 3] = 2.5
+    W, H = 112, 80
+    K = torch.tensor([[[80.0, 0, W / 2], [0, 80.0, H / 2], [0, 0, 1]]])
+    cpu, gpu, out_c, out_g = _run_both(R, sc, vm, K, W, H, tight=tight)
+    mg = out_g[2]
+    d = mg["depths"].detach().cpu()[0]
+    vis = (mg["radii"].cpu()[0] > 0).all(-1)
+    assert float(d[vis].min()) == float(d[vis].max())                 # really one depth
+    tw, th = mg["tile_width"], mg["tile_height"]
+    counts = torch.diff(torch.cat([mg["isect_offsets"].reshape(-1).cpu(),
+                                   torch.tensor([mg["flatten_ids"].numel()], dtype=torch.int32)]))
+    assert int(counts.max()) > 200                                     # longer than a depth bin may be (160)
+    if not tight:
+        tpg, ids, flat = O.isect_tiles_fast(mg["means2d"].detach().cpu(), mg["radii"].cpu(), mg["depths"].detach().cpu(), 16, tw, th)
+        assert torch.equal(mg["flatten_ids"].cpu(), flat)
+        assert torch.equal(mg["isect_offsets"].cpu(), O.isect_offset_encode(ids, 1, tw, th))
+    # inside every tile the list is in index order (the tie-break), tight or not
+    off = mg["isect_offsets"].reshape(-1).long().cpu()
+    fl = mg["flatten_ids"].long().cpu()
+    tile_of = torch.bucketize(torch.arange(fl.numel()), off, right=True)
+    same = tile_of[1:] == tile_of[:-1]
+    assert (fl[1:][same] > fl[:-1][same]).all()
+    _check(cpu, gpu, out_c, out_g)
+
+
 def test_tiny_split_sh_layout(R):
     sc, vm, K, W, H = _tiny()
     _check(*_run_both(R, sc, vm, K, W, H, split=True))
