@@ -568,7 +568,8 @@ constexpr int BK_BIN_TARGET = GSR_BIN_TARGET;   // keys per bin aimed at
 constexpr int BK_BIN_MAX = 160;        // longer bins: fall back to the networks
 constexpr int BK_KPT = BK_SORT_CAP / BK_THREADS;   // keys per thread when a whole bucket is in flight (8)
 
-__global__ void __launch_bounds__(BK_THREADS)
+// (<= 64 VGPRs: two 1024-thread workgroups per CU)
+__global__ void __launch_bounds__(BK_THREADS, 8)
 bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict__ bucket_offsets,
                    const int32_t *__restrict__ bucket_order, const int32_t *__restrict__ real_counts,
                    uint64_t *__restrict__ keys, uint64_t *__restrict__ keys_sorted,
@@ -578,7 +579,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   __shared__ uint64_t sk[BK_SORT_CAP];
   __shared__ int32_t bins[BK_MAX_BINS + 8], cur[BK_MAX_BINS];
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
-  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s;
+  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s, grp_tile[BK_TILES + 2], n_grp_s;
   __shared__ int32_t red[BK_THREADS / 64], out_base_s, maxbin_s;
   __shared__ uint32_t dmin_s, dmax_s;
   const int tid = threadIdx.x;
@@ -608,10 +609,17 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
 #pragma unroll
       for (int u = 0; u < BK_KPT; ++u)
         if (kreg[u] != BK_SENTINEL) f(kreg[u]);
-    } else {
-      for (int t = tid; t < LA; t += BK_THREADS) {
-        const uint64_t k = keys[s + t];
-        if (k != BK_SENTINEL) f(k);
+    } else {   // (eight loads in flight per thread: one at a time, each pass over a 12 000-key region cost 15 round trips)
+      for (int base = 0; base < LA; base += BK_SORT_CAP) {
+        uint64_t kk[BK_KPT];
+#pragma unroll
+        for (int u = 0; u < BK_KPT; ++u) {
+          const int t = base + tid + u * BK_THREADS;
+          kk[u] = t < LA ? keys[s + t] : BK_SENTINEL;
+        }
+#pragma unroll
+        for (int u = 0; u < BK_KPT; ++u)
+          if (kk[u] != BK_SENTINEL) f(kk[u]);
       }
     }
   };
@@ -628,10 +636,10 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     }
     for (int i = tid; i < BK_MAX_BINS + 8; i += BK_THREADS) bins[i] = 0;
     __syncthreads();
-    if (tid == 0) {
-      int t = 0;
-      for (int w = 0; w < BK_THREADS / 64; ++w) t += red[w];
-      out_base_s = t;
+    if (tid < 64) {     // (a wave sum, not one thread adding the sixteen: that block's wide LDS reads were the kernel's
+                        // register peak)
+      const int t = wave_sum_i32(tid < BK_THREADS / 64 ? red[tid] : 0);
+      if (tid == 0) out_base_s = t;
     }
     for_keys([&](uint64_t k) {
       const uint32_t d = depth_of(k);
@@ -677,7 +685,25 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     if ((tid & 63) == 0 && m > 0) atomicMax(&maxbin_s, m);
   }
   const int L = bk_block_exclusive_scan(bins, nbins, wave_tot);   // bins = start of every (tile, depth bin); L = real pairs
-  if (tid == 0) bins[nbins] = L;
+  if (tid == 0) {
+    bins[nbins] = L;
+    // groups of consecutive tiles whose lists fit the LDS sorter together: ONE group when the whole bucket does
+    // (c4: 2 200 pairs per bucket), two or three for the long buckets of a dense scene (2 M Gaussians seeded from
+    // depth maps at 1080p: 12 000 pairs per bucket, 2 000 per tile -- round 4 sent those to the global-memory
+    // network below: 1.25 ms per frame, now 0.118). No group at all (n_grp 0) when ONE tile's list exceeds the sorter.
+    int ng = 0, q0 = 0;
+    bool ok = true;
+    grp_tile[0] = 0;
+    for (int q = 0; q < BK_TILES; ++q) {
+      if (bins[(q + 1) * NB] - bins[q * NB] > BK_SORT_CAP) ok = false;
+      if (q > q0 && bins[(q + 1) * NB] - bins[q0 * NB] > BK_SORT_CAP) {
+        grp_tile[++ng] = q;
+        q0 = q;
+      }
+    }
+    grp_tile[++ng] = BK_TILES;
+    n_grp_s = ok ? ng : 0;
+  }
   for (int i = tid; i < nbins; i += BK_THREADS) cur[i] = bins[i];
   __syncthreads();
   auto put = [&](int t, uint64_t k) {
@@ -688,38 +714,40 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       if (keys_sorted) keys_sorted[o] = k;
     }
   };
-  if (L <= BK_SORT_CAP) {
-    for_keys([&](uint64_t k) { sk[atomicAdd(&cur[bin_of(k)], 1)] = k; });
+  const int n_grp = n_grp_s;
+  const bool by_rank = maxbin_s <= BK_BIN_MAX;
+  // one group: tiles [q0, q1) = the slice [g0, g0 + Lg) of the bucket's sorted order; `walk` hands over the bucket's keys
+  auto sort_group = [&](int q0, int q1, auto &&walk) {
+    const int g0 = bins[q0 * NB], Lg = bins[q1 * NB] - g0;
+    walk([&](uint64_t k) {
+      const int q = (int)(k >> 61);
+      if (q >= q0 && q < q1) sk[atomicAdd(&cur[bin_of(k)], 1) - g0] = k;
+    });
     __syncthreads();
     SORT_STAMP(3);
-    if (maxbin_s <= BK_BIN_MAX) {
-      // every key's rank inside its bin (ranks first, from the unmodified split; then the permutation in place)
-      uint64_t mine[BK_KPT];
-      int dst[BK_KPT];
-#pragma unroll
-      for (int u = 0; u < BK_KPT; ++u) {
-        const int p = tid + u * BK_THREADS;
-        dst[u] = -1;
-        if (p < L) {
-          const uint64_t k = sk[p];
-          const int bn = bin_of(k);
-          const int s0 = bins[bn], e0 = bins[bn + 1];
-          int rank = 0;
-          for (int j = s0; j < e0; ++j) rank += sk[j] < k ? 1 : 0;
-          mine[u] = k;
-          dst[u] = s0 + rank;
-        }
+    if (by_rank) {
+      // every key's rank inside its bin gives its final position: written straight to the lists (a wave's 64
+      // consecutive keys sit in neighbouring bins, so its stores fall into the same few lines). Ranks first, then
+      // a permutation inside LDS and coalesced stores -- round 4's first version -- holds eight keys and positions
+      // per thread across a barrier: 0.037 vs 0.036 ms at c4, and kept live beside the group loop it cost the second
+      // workgroup per CU (> 64 VGPRs) or spilled (dense scene 0.138 vs 0.118 ms).
+      for (int p = tid; p < Lg; p += BK_THREADS) {
+        const uint64_t k = sk[p];
+        const int bn = bin_of(k);
+        const int s0 = bins[bn] - g0, e0 = bins[bn + 1] - g0;
+        int rank = 0;
+        for (int j = s0; j < e0; ++j) rank += sk[j] < k ? 1 : 0;
+        put(g0 + s0 + rank, k);
       }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < BK_KPT; ++u)
-        if (dst[u] >= 0) sk[dst[u]] = mine[u];
-      __syncthreads();
+      SORT_STAMP(4);
+      SORT_STAMP(5);
+      return;
     } else {
-      // many equal depths in one bin: the round-3 networks on the eight tile segments the split has laid out
+      // many equal depths in one bin: the round-3 networks on the tile segments the split has laid out
       if (tid < BK_TILES) {
-        seg_start[tid] = bins[tid * NB];
-        seg_cnt[tid] = bins[(tid + 1) * NB] - bins[tid * NB];
+        const bool in = tid >= q0 && tid < q1;
+        seg_start[tid] = in ? bins[tid * NB] - g0 : 0;
+        seg_cnt[tid] = in ? bins[(tid + 1) * NB] - bins[tid * NB] : 0;
       }
       __syncthreads();
       if (tid == 0) {
@@ -734,10 +762,24 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
     }
     SORT_STAMP(4);
-    for (int t = tid; t < L; t += BK_THREADS) put(t, sk[t]);
+    for (int t = tid; t < Lg; t += BK_THREADS) put(g0 + t, sk[t]);
     SORT_STAMP(5);
-  } else {   // longer than the LDS sorter: one composite-key network in global memory (slow, exact);
-             // sentinels are the largest key and end up behind the L real ones
+  };
+  if (in_regs) {       // the whole region fits the sorter: always one group, the keys still in registers (and dead
+                       // afterwards: kept live across the group loop below they cost the second workgroup per CU)
+    sort_group(0, BK_TILES, [&](auto &&f) {
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u)
+        if (kreg[u] != BK_SENTINEL) f(kreg[u]);
+    });
+  } else {
+    for (int g = 0; g < n_grp; ++g) {
+      sort_group(grp_tile[g], grp_tile[g + 1], for_keys);
+      if (g + 1 < n_grp) __syncthreads();                // the next group's split overwrites sk
+    }
+  }
+  if (n_grp == 0) {   // one tile alone exceeds the LDS sorter: one composite-key network in global memory (slow,
+                      // exact); sentinels are the largest key and end up behind the L real ones
     bk_bitonic<false>(keys + s, LA, tid);
     for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);
   }

@@ -36,6 +36,7 @@ ap.add_argument("--views", type=int, default=100)
 ap.add_argument("--result-dir", default="/tmp/c5_rehearsal")      # (checkpoints of a few GB: not under gpurun_out)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--isect-stats", action="store_true", help="print the tile-list / bucket length distribution of the seed cloud and of the trained scene")
 args = ap.parse_args()
 P = "3dgs_monocular_depth_init_amd."
 runner = importlib.import_module(P + "runner")
@@ -128,6 +129,29 @@ splats, opts = runner.create_splats_with_optimizers(pts, rgbs, log_scales, init_
 n_init = len(pts)
 del pts, rgbs, log_scales, depths, alphas
 
+def isect_stats(tag):
+    """Lengths of the tile lists and of the 8-tile buckets the sort kernel works on (isect_bucket.hip), five views."""
+    out = []
+    with torch.no_grad():
+        for i in range(0, args.views, max(args.views // 5, 1)):
+            _, _, info = runner.rasterize_splats(splats, c2ws[i:i + 1], Ks[i:i + 1], W, H, sh_degree=0)
+            off = info["isect_offsets"].reshape(-1).long()
+            total = int(info["flatten_ids"].shape[0])
+            lens = torch.diff(torch.cat([off, off.new_tensor([total])])).view(info["tile_height"], info["tile_width"])
+            tw = lens.shape[1]
+            pad = (-tw) % 8
+            b = torch.nn.functional.pad(lens, (0, pad)).view(lens.shape[0], -1, 8).sum(-1).flatten().float()
+            q = lambda x, f: int(torch.quantile(x.flatten().float(), f))
+            out.append({"view": i, "pairs": total, "tile_max": int(lens.max()), "tile_p99": q(lens, 0.99), "bucket_mean": int(b.mean()),
+                        "bucket_p50": q(b, 0.5), "bucket_p90": q(b, 0.9), "bucket_max": int(b.max()),
+                        "buckets_over_8192": int((b > 8192).sum()), "buckets": int(b.numel()),
+                        "pairs_in_buckets_over_8192": round(float(b[b > 8192].sum() / b.sum()), 3)})
+    print(json.dumps({"isect_stats": tag, "num_GS": len(splats["means"]), "views": out}), flush=True)
+
+
+if args.isect_stats:
+    isect_stats("seed cloud")
+
 # ---- 3. the loop ----------------------------------------------------------------------------------------------
 cfg.adjust_steps(args.steps_scaler)
 every = max(int(1000 * args.steps_scaler), 1)
@@ -140,6 +164,8 @@ def progress(step, rec):
 torch.cuda.reset_peak_memory_stats()
 stats = runner.train(splats, opts, train_frames, cfg, valset=val_frames, scene_scale=scene_scale, result_dir=args.result_dir,
                      progress=progress, progress_every=every)
+if args.isect_stats:
+    isect_stats("after %d steps" % stats["steps"])
 ck = sorted(Path(args.result_dir, "ckpts").glob("*"))
 losses = [r["loss"] for r in stats["intervals"]]
 rec = {
