@@ -579,7 +579,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   __shared__ uint64_t sk[BK_SORT_CAP];
   __shared__ int32_t bins[BK_MAX_BINS + 8], cur[BK_MAX_BINS];
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
-  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s, grp_tile[BK_TILES + 2], n_grp_s;
+  __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s;
   __shared__ int32_t red[BK_THREADS / 64], out_base_s, maxbin_s;
   __shared__ uint32_t dmin_s, dmax_s;
   const int tid = threadIdx.x;
@@ -685,25 +685,7 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     if ((tid & 63) == 0 && m > 0) atomicMax(&maxbin_s, m);
   }
   const int L = bk_block_exclusive_scan(bins, nbins, wave_tot);   // bins = start of every (tile, depth bin); L = real pairs
-  if (tid == 0) {
-    bins[nbins] = L;
-    // groups of consecutive tiles whose lists fit the LDS sorter together: ONE group when the whole bucket does
-    // (c4: 2 200 pairs per bucket), two or three for the long buckets of a dense scene (2 M Gaussians seeded from
-    // depth maps at 1080p: 12 000 pairs per bucket, 2 000 per tile -- round 4 sent those to the global-memory
-    // network below: 1.25 ms per frame, now 0.118). No group at all (n_grp 0) when ONE tile's list exceeds the sorter.
-    int ng = 0, q0 = 0;
-    bool ok = true;
-    grp_tile[0] = 0;
-    for (int q = 0; q < BK_TILES; ++q) {
-      if (bins[(q + 1) * NB] - bins[q * NB] > BK_SORT_CAP) ok = false;
-      if (q > q0 && bins[(q + 1) * NB] - bins[q0 * NB] > BK_SORT_CAP) {
-        grp_tile[++ng] = q;
-        q0 = q;
-      }
-    }
-    grp_tile[++ng] = BK_TILES;
-    n_grp_s = ok ? ng : 0;
-  }
+  if (tid == 0) bins[nbins] = L;
   for (int i = tid; i < nbins; i += BK_THREADS) cur[i] = bins[i];
   __syncthreads();
   auto put = [&](int t, uint64_t k) {
@@ -714,14 +696,30 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       if (keys_sorted) keys_sorted[o] = k;
     }
   };
-  const int n_grp = n_grp_s;
-  const bool by_rank = maxbin_s <= BK_BIN_MAX;
-  // one group: tiles [q0, q1) = the slice [g0, g0 + Lg) of the bucket's sorted order; `walk` hands over the bucket's keys
-  auto sort_group = [&](int q0, int q1, auto &&walk) {
-    const int g0 = bins[q0 * NB], Lg = bins[q1 * NB] - g0;
+  // Groups of consecutive bins that fit the LDS sorter together: ONE group when the whole bucket does (c4: 2 200
+  // pairs per bucket); otherwise group j = the bins that start inside [j C, (j + 1) C) of the bucket's sorted order,
+  // fewer than C + (largest bin) keys. A dense scene (2 M Gaussians seeded from depth maps at 1080p: 12 000 pairs per
+  // bucket, 2 000 per tile) takes two groups; round 4 sent such buckets to the global-memory network at the bottom:
+  // 1.25 ms per frame, now 0.118. A single tile list may be longer than the sorter, too. Only a BIN that does not
+  // fit (thousands of equal depths in one tile) leaves no grouping (n_grp 0).
+  const int maxbin = maxbin_s;
+  const bool by_rank = maxbin <= BK_BIN_MAX, whole = L <= BK_SORT_CAP;
+  const int C = by_rank ? BK_SORT_CAP - BK_BIN_MAX : BK_SORT_CAP / 2;
+  const int n_grp = whole ? 1 : (maxbin <= BK_SORT_CAP - C ? (L + C - 1) / C : 0);
+  auto first_bin_from = [&](int pos) {     // first bin whose start is >= pos (uniform: every thread searches)
+    int lo = 0, hi = nbins;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bins[mid] < pos) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  // one group: bins [b0, b1) = the slice [g0, g0 + Lg) of the bucket's sorted order; `walk` hands over the bucket's keys
+  auto sort_group = [&](int b0, int b1, auto &&walk) {
+    const int g0 = bins[b0], Lg = bins[b1] - g0;
     walk([&](uint64_t k) {
-      const int q = (int)(k >> 61);
-      if (q >= q0 && q < q1) sk[atomicAdd(&cur[bin_of(k)], 1) - g0] = k;
+      const int bn = bin_of(k);
+      if (bn >= b0 && bn < b1) sk[atomicAdd(&cur[bn], 1) - g0] = k;
     });
     __syncthreads();
     SORT_STAMP(3);
@@ -742,12 +740,12 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       SORT_STAMP(4);
       SORT_STAMP(5);
       return;
-    } else {
-      // many equal depths in one bin: the round-3 networks on the tile segments the split has laid out
+    }
+    // many equal depths in one bin: compare-exchange networks instead of ranks
+    if (whole) {      // the round-3 networks on the eight tile segments the split has laid out
       if (tid < BK_TILES) {
-        const bool in = tid >= q0 && tid < q1;
-        seg_start[tid] = in ? bins[tid * NB] - g0 : 0;
-        seg_cnt[tid] = in ? bins[(tid + 1) * NB] - bins[tid * NB] : 0;
+        seg_start[tid] = bins[tid * NB];
+        seg_cnt[tid] = bins[(tid + 1) * NB] - bins[tid * NB];
       }
       __syncthreads();
       if (tid == 0) {
@@ -760,6 +758,8 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       __syncthreads();
       const int grp = tid >> 7;                          // 8 groups of 128 threads
       bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+    } else {          // one network over the group (the tile is the top of the key)
+      bk_bitonic<true>(sk, Lg, tid);
     }
     SORT_STAMP(4);
     for (int t = tid; t < Lg; t += BK_THREADS) put(g0 + t, sk[t]);
@@ -767,18 +767,19 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   };
   if (in_regs) {       // the whole region fits the sorter: always one group, the keys still in registers (and dead
                        // afterwards: kept live across the group loop below they cost the second workgroup per CU)
-    sort_group(0, BK_TILES, [&](auto &&f) {
+    sort_group(0, nbins, [&](auto &&f) {
 #pragma unroll
       for (int u = 0; u < BK_KPT; ++u)
         if (kreg[u] != BK_SENTINEL) f(kreg[u]);
     });
   } else {
     for (int g = 0; g < n_grp; ++g) {
-      sort_group(grp_tile[g], grp_tile[g + 1], for_keys);
+      const int b0 = whole ? 0 : first_bin_from(g * C), b1 = (whole || g + 1 == n_grp) ? nbins : first_bin_from((g + 1) * C);
+      sort_group(b0, b1, for_keys);
       if (g + 1 < n_grp) __syncthreads();                // the next group's split overwrites sk
     }
   }
-  if (n_grp == 0) {   // one tile alone exceeds the LDS sorter: one composite-key network in global memory (slow,
+  if (n_grp == 0) {   // one BIN alone exceeds what a group may hold: one composite-key network in global memory (slow,
                       // exact); sentinels are the largest key and end up behind the L real ones
     bk_bitonic<false>(keys + s, LA, tid);
     for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);

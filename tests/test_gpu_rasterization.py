@@ -277,7 +277,8 @@ def test_empty_and_offscreen(R):
 
 
 def test_long_tile_lists(R):
-    """All Gaussians in one tile: exercises the >2048 and >8192 sort paths."""
+    """All Gaussians in one tile: a single tile list longer than the LDS sorter (8192), sorted in two groups of
+    depth bins."""
     N = 9000
     g = torch.Generator().manual_seed(1)
     sc = scenes.make_scene(N, 2, box=(0.02, 0.02, 0.5), scale_mean=0.002)
@@ -296,20 +297,21 @@ def test_long_tile_lists(R):
     _check(cpu, gpu, out_c, out_g)
 
 
-@pytest.mark.parametrize("case", ["spread", "equal_depths", "one_big_tile"])
+@pytest.mark.parametrize("case", ["spread", "equal_depths", "one_big_tile", "equal_depths_one_big_tile"])
 def test_long_buckets_of_short_tile_lists(R, case):
     """A bucket (8 adjacent tiles, the unit the sort kernel works on) holding more pairs than the LDS sorter
-    takes (8192) while every tile list fits: the dense-scene case (2 M Gaussians seeded from depth maps at 1080p:
-    12 000 pairs per bucket, 2 000 per tile), sorted tile group by tile group (isect_bucket.hip). With equal depths
-    every depth bin overflows and the groups take the compare-exchange networks instead of the in-bin ranks; with
-    one tile of 4096 < n <= 8192 pairs that tile is a group of its own (ranks stored directly). The lists must
-    equal the oracle's full sort, image and gradients the oracle's."""
+    takes (8192): the dense-scene case (2 M Gaussians seeded from depth maps at 1080p: 12 000 pairs per bucket,
+    2 000 per tile), sorted group by group of consecutive (tile, depth) bins (isect_bucket.hip). With equal depths
+    every tile is ONE bin and the groups take compare-exchange networks instead of the in-bin ranks; with equal
+    depths and one tile of more than 4096 pairs no grouping is left and the bucket takes the global-memory network.
+    (test_long_tile_lists: one tile list alone longer than the sorter.) The lists must equal the oracle's full sort,
+    image and gradients the oracle's."""
     N = 18000
     sc = scenes.make_scene(N, 6, box=(1.8, 0.2, 0.3), scale_mean=0.002)
     sc["opacities"] = torch.full((N,), 0.02)
-    if case == "equal_depths":
+    if case.startswith("equal_depths"):
         sc["means"][:, 2] = 0.125
-    if case == "one_big_tile":                      # 5 000 of them inside the third tile of the middle row
+    if case.endswith("one_big_tile"):                      # 5 000 of them inside the third tile of the middle row
         sc["means"][:5000, 0] = -0.8 + 0.15 * (torch.rand(5000, generator=torch.Generator().manual_seed(8)) - 0.5)
     vm = torch.eye(4)[None].clone()
     vm[0, 2, 3] = 2.0
@@ -323,7 +325,7 @@ def test_long_buckets_of_short_tile_lists(R, case):
     counts = torch.diff(torch.cat([mg["isect_offsets"].reshape(-1).cpu(),
                                    torch.tensor([flat.numel()], dtype=torch.int32)])).view(H // 16, W // 16)
     assert counts.max().item() <= 8192 and counts.sum(1).max().item() > 2 * 8192      # three groups at least
-    assert (counts.max().item() > 4096) == (case == "one_big_tile")
+    assert (counts.max().item() > 4096) == case.endswith("one_big_tile")
     # (a 128 x 48 image: ONE threshold-boundary pixel is three of 18 432 values, 1.6e-4 of them)
     _check(cpu, gpu, out_c, out_g, flip_frac=2e-4)
 
