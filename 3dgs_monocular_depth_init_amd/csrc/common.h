@@ -217,6 +217,35 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// All-lanes reductions of a 32-bit value without lane-address registers: four DPP steps inside the rows, then the
+// two lane-swap instructions (a = b = v: every lane ends with the folded value). The __shfl_xor versions above need
+// six address VGPRs (ds_bpermute), which the compiler computes once and keeps live across a whole kernel.
+template <typename Op>
+__device__ __forceinline__ int wave_allreduce_i32(int v, Op op) {
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+  {
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    v = op((int)r0, (int)r1);
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    v = op((int)r0, (int)r1);
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) { return wave_allreduce_i32(v, [](int a, int b) { return a + b; }); }
+__device__ __forceinline__ int wave_max_i32_dpp(int v) { return wave_allreduce_i32(v, [](int a, int b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+  return (uint32_t)wave_allreduce_i32((int)v, [](int a, int b) { return (uint32_t)a < (uint32_t)b ? a : b; });
+}
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+  return (uint32_t)wave_allreduce_i32((int)v, [](int a, int b) { return (uint32_t)a > (uint32_t)b ? a : b; });
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

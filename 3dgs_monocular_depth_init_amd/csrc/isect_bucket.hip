@@ -23,6 +23,7 @@
 // pass fills what it does not use with sentinels, and the sort pass compacts. Tight lists render the same image and gradients (the
 // dropped pairs contribute alpha < 1/255 everywhere, which both rules discard); the default
 // keeps gsplat's lists bit for bit.
+#include <type_traits>
 #include "raster_common.h"
 
 namespace gsr {
@@ -560,12 +561,13 @@ __device__ unsigned long long *g_sort_timeline = nullptr;
 // (tile, depth) and the in-bin rank uses the whole composite key, so the result is exactly the order of
 // the full sort. A bucket in which some bin holds more than BK_BIN_MAX keys (many equal depths) takes the
 // round-3 networks on the tile segments instead (which the split has already laid out).
-constexpr int BK_MAX_BINS = 1024;      // 8 tiles x up to 128 depth bins
+constexpr int BK_MAX_BINS = 960;       // 8 tiles x up to 120 depth bins (four tables of them beside the 64 KB of keys: 2 workgroups per CU)
 #ifndef GSR_BIN_TARGET
 #define GSR_BIN_TARGET 4
 #endif
 constexpr int BK_BIN_TARGET = GSR_BIN_TARGET;   // keys per bin aimed at
 constexpr int BK_BIN_MAX = 160;        // longer bins: fall back to the networks
+constexpr int BK_BIN_EQ = 24;          // a bin this long (uniform depths: <= 15) -> the bins are equalised, see below
 constexpr int BK_KPT = BK_SORT_CAP / BK_THREADS;   // keys per thread when a whole bucket is in flight (8)
 
 // (<= 64 VGPRs: two 1024-thread workgroups per CU)
@@ -577,11 +579,13 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
                    int32_t *__restrict__ tile_offsets, int n_tiles, int capacity,
                    int32_t *__restrict__ clear_counts, int32_t *__restrict__ total_host) {
   __shared__ uint64_t sk[BK_SORT_CAP];
-  __shared__ int32_t bins[BK_MAX_BINS + 8], cur[BK_MAX_BINS];
+  __shared__ int32_t bins[BK_MAX_BINS + 8], cur[BK_MAX_BINS], cdf[BK_MAX_BINS + 8];
+  __shared__ uint32_t occ[BK_MAX_BINS];
   __shared__ int32_t wave_tot[BK_THREADS / 64 + 1];
   __shared__ int seg_cnt[BK_TILES], seg_start[BK_TILES + 1], npad_max_s;
   __shared__ int32_t red[BK_THREADS / 64], out_base_s, maxbin_s;
   __shared__ uint32_t dmin_s, dmax_s;
+  __shared__ float sumsq_s;
   const int tid = threadIdx.x;
   SORT_STAMP(0);
   const int b = bucket_order ? bucket_order[blockIdx.x] : (int)blockIdx.x;
@@ -614,8 +618,8 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
         uint64_t kk[BK_KPT];
 #pragma unroll
         for (int u = 0; u < BK_KPT; ++u) {
-          const int t = base + tid + u * BK_THREADS;
-          kk[u] = t < LA ? keys[s + t] : BK_SENTINEL;
+          int t = base + tid + u * BK_THREADS;
+            kk[u] = t < LA ? keys[s + t] : BK_SENTINEL;
         }
 #pragma unroll
         for (int u = 0; u < BK_KPT; ++u)
@@ -627,18 +631,20 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   {
     int acc = 0;
     for (int i = tid; i < b; i += BK_THREADS) acc += real_counts[i];
-    acc = wave_sum_i32(acc);
+    acc = wave_sum_i32_dpp(acc);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     if (tid == 0) {
       dmin_s = 0xffffffffu;
       dmax_s = 0u;
       maxbin_s = 0;
+      sumsq_s = 0.f;
     }
     for (int i = tid; i < BK_MAX_BINS + 8; i += BK_THREADS) bins[i] = 0;
+    if (tid < BK_MAX_BINS) occ[tid] = 0u;
     __syncthreads();
     if (tid < 64) {     // (a wave sum, not one thread adding the sixteen: that block's wide LDS reads were the kernel's
                         // register peak)
-      const int t = wave_sum_i32(tid < BK_THREADS / 64 ? red[tid] : 0);
+      const int t = wave_sum_i32_dpp(tid < BK_THREADS / 64 ? red[tid] : 0);
       if (tid == 0) out_base_s = t;
     }
     for_keys([&](uint64_t k) {
@@ -646,11 +652,8 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       mn = min(mn, d);
       mx = max(mx, d);
     });
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
-      mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-    }
+    mn = wave_min_u32_dpp(mn);
+    mx = wave_max_u32_dpp(mx);
     if ((tid & 63) == 0 && mn <= mx) {
       atomicMin(&dmin_s, mn);
       atomicMax(&dmax_s, mx);
@@ -669,25 +672,63 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
   // monotone in the depth bits: float subtraction and multiplication by a positive constant round
   // monotonically, truncation is monotone, the clamps keep both edges inside (and send a NaN, which no
   // finite depth produces here, to bin 0 instead of an out-of-range index)
-  auto bin_of = [&](uint64_t k) {
-    const float t = (__uint_as_float(depth_of(k)) - fmin) * bscale;
-    const int db = t >= 0.f ? (t < (float)NB ? (int)t : NB - 1) : 0;
-    return (int)(k >> 61) * NB + db;
-  };
+  //
+  // Equalised bins. Real scenes put a tile's Gaussians on a few surfaces: depths in clusters, gaps between them, the
+  // range set by a floater -- linear bins over [min, max] then hold dozens of keys each and the in-bin ranks go
+  // quadratic (c4's Gaussians on two thin shells: 0.028 -> 0.061 ms, tools/sort_depth_clusters.sh). When a level-1 bin
+  // exceeds BK_BIN_EQ keys the bins are re-drawn: every level-1 bin records which of its 32 sub-intervals are occupied
+  // (`occ`), and a key's position inside its tile is taken as (keys of the tile in earlier level-1 bins) + (its bin's
+  // count) x (occupied sub-intervals before its own + its fraction of its own) / (occupied sub-intervals) -- the
+  // tile's empirical distribution, resolved to 1 / (32 NB) of the range; the level-2 bin is that position scaled to
+  // NB bins. Monotone in the depth bits like level 1: inside a sub-interval, across sub-intervals and across level-1
+  // bins the position never decreases (counts are integers below 2^24, every float operation rounds monotonically).
   const int nbins = BK_TILES * NB;
-  for_keys([&](uint64_t k) { atomicAdd(&bins[bin_of(k)], 1); });
-  __syncthreads();
-  SORT_STAMP(2);
-  {
+  auto level1 = [&](uint64_t k, float &t) {      // level-1 depth bin of a key, and its coordinate t in bins
+    t = (__uint_as_float(depth_of(k)) - fmin) * bscale;
+    return t >= 0.f ? (t < (float)NB ? (int)t : NB - 1) : 0;
+  };
+  auto sub_of = [&](float t, int d1, float &us) {   // which of the 32 sub-intervals of its level-1 bin
+    us = fminf(fmaxf(t - (float)d1, 0.f), 1.f) * 32.f;
+    return min(31, (int)us);
+  };
+  auto bin1 = [&](uint64_t k) {
+    float t;
+    return (int)(k >> 61) * NB + level1(k, t);
+  };
+  auto bin2 = [&](uint64_t k) {
+    float t, us;
+    const int q = (int)(k >> 61), d1 = level1(k, t), b1 = q * NB + d1, sub = sub_of(t, d1, us);
+    const uint32_t m = occ[b1];
+    const float w = ((float)__popc(m & ((1u << sub) - 1u)) + fminf(us - (float)sub, 1.f)) * __builtin_amdgcn_rcpf((float)max(1, __popc(m)));
+    const int t0 = cdf[q * NB], c0 = cdf[b1], c1 = cdf[b1 + 1], t1 = cdf[(q + 1) * NB];
+    const float pos = (float)(c0 - t0) + fminf(w, 1.f) * (float)(c1 - c0);
+    const int d2 = (int)(pos * ((float)NB * __builtin_amdgcn_rcpf((float)max(1, t1 - t0))));   // (a positive constant per tile)
+    return q * NB + min(NB - 1, max(0, d2));
+  };
+  auto stream_keys = [&](auto &&f) {      // the bucket's keys from global memory (L2), eight loads in flight per thread:
+                                          // one at a time, each pass over a 12 000-key region cost 15 round trips
+    for (int base = 0; base < LA; base += BK_SORT_CAP) {
+      uint64_t kk[BK_KPT];
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u) {
+        const int t = base + tid + u * BK_THREADS;
+        kk[u] = t < LA ? keys[s + t] : BK_SENTINEL;
+      }
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u)
+        if (kk[u] != BK_SENTINEL) f(kk[u]);
+    }
+  };
+  auto histogram = [&](auto &&bin_fn, auto &&walk) {      // bins = keys per bin; returns the largest
+    walk([&](uint64_t k) { atomicAdd(&bins[bin_fn(k)], 1); });
+    __syncthreads();
     int m = 0;
     for (int i = tid; i < nbins; i += BK_THREADS) m = max(m, bins[i]);
-    m = wave_max_i32(m);
+    m = wave_max_i32_dpp(m);
     if ((tid & 63) == 0 && m > 0) atomicMax(&maxbin_s, m);
-  }
-  const int L = bk_block_exclusive_scan(bins, nbins, wave_tot);   // bins = start of every (tile, depth bin); L = real pairs
-  if (tid == 0) bins[nbins] = L;
-  for (int i = tid; i < nbins; i += BK_THREADS) cur[i] = bins[i];
-  __syncthreads();
+    __syncthreads();
+    return maxbin_s;
+  };
   auto put = [&](int t, uint64_t k) {
     const int64_t o = (int64_t)out_base + t;
     if (o < capacity) {
@@ -696,93 +737,159 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
       if (keys_sorted) keys_sorted[o] = k;
     }
   };
-  // Groups of consecutive bins that fit the LDS sorter together: ONE group when the whole bucket does (c4: 2 200
-  // pairs per bucket); otherwise group j = the bins that start inside [j C, (j + 1) C) of the bucket's sorted order,
-  // fewer than C + (largest bin) keys. A dense scene (2 M Gaussians seeded from depth maps at 1080p: 12 000 pairs per
-  // bucket, 2 000 per tile) takes two groups; round 4 sent such buckets to the global-memory network at the bottom:
-  // 1.25 ms per frame, now 0.118. A single tile list may be longer than the sorter, too. Only a BIN that does not
-  // fit (thousands of equal depths in one tile) leaves no grouping (n_grp 0).
-  const int maxbin = maxbin_s;
-  const bool by_rank = maxbin <= BK_BIN_MAX, whole = L <= BK_SORT_CAP;
-  const int C = by_rank ? BK_SORT_CAP - BK_BIN_MAX : BK_SORT_CAP / 2;
-  const int n_grp = whole ? 1 : (maxbin <= BK_SORT_CAP - C ? (L + C - 1) / C : 0);
-  auto first_bin_from = [&](int pos) {     // first bin whose start is >= pos (uniform: every thread searches)
-    int lo = 0, hi = nbins;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (bins[mid] < pos) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  // one group: bins [b0, b1) = the slice [g0, g0 + Lg) of the bucket's sorted order; `walk` hands over the bucket's keys
-  auto sort_group = [&](int b0, int b1, auto &&walk) {
-    const int g0 = bins[b0], Lg = bins[b1] - g0;
-    walk([&](uint64_t k) {
-      const int bn = bin_of(k);
-      if (bn >= b0 && bn < b1) sk[atomicAdd(&cur[bn], 1) - g0] = k;
-    });
+  int L = 0;
+  // everything after the histogram: scan, split, ranks (or networks), lists. Two instances: level-1 bins with the keys
+  // in registers when they fit, and equalised bins on keys parked in LDS (or streamed, long buckets)
+  auto finish = [&](int maxbin, auto &&bin_fn, auto &&resident_keys) {
+    L = bk_block_exclusive_scan(bins, nbins, wave_tot);   // bins = start of every (tile, depth bin); L = real pairs
+    if (tid == 0) bins[nbins] = L;
+    for (int i = tid; i < nbins; i += BK_THREADS) cur[i] = bins[i];
     __syncthreads();
-    SORT_STAMP(3);
-    if (by_rank) {
-      // every key's rank inside its bin gives its final position: written straight to the lists (a wave's 64
-      // consecutive keys sit in neighbouring bins, so its stores fall into the same few lines). Ranks first, then
-      // a permutation inside LDS and coalesced stores -- round 4's first version -- holds eight keys and positions
-      // per thread across a barrier: 0.037 vs 0.036 ms at c4, and kept live beside the group loop it cost the second
-      // workgroup per CU (> 64 VGPRs) or spilled (dense scene 0.138 vs 0.118 ms).
-      for (int p = tid; p < Lg; p += BK_THREADS) {
-        const uint64_t k = sk[p];
-        const int bn = bin_of(k);
-        const int s0 = bins[bn] - g0, e0 = bins[bn + 1] - g0;
-        int rank = 0;
-        for (int j = s0; j < e0; ++j) rank += sk[j] < k ? 1 : 0;
-        put(g0 + s0 + rank, k);
+    // Groups of consecutive bins that fit the LDS sorter together: ONE group when the whole bucket does (c4: 2 200
+    // pairs per bucket); otherwise group j = the bins that start inside [j C, (j + 1) C) of the bucket's sorted order,
+    // fewer than C + (largest bin) keys. A dense scene (2 M Gaussians seeded from depth maps at 1080p: 12 000 pairs per
+    // bucket, 2 000 per tile) takes two groups; round 4 sent such buckets to the global-memory network at the bottom:
+    // 1.25 ms per frame, now 0.118. A single tile list may be longer than the sorter, too. Only a BIN that does not
+    // fit (thousands of equal depths in one tile) leaves no grouping (n_grp 0).
+    const bool by_rank = maxbin <= BK_BIN_MAX, whole = L <= BK_SORT_CAP;
+    const int C = by_rank ? BK_SORT_CAP - BK_BIN_MAX : BK_SORT_CAP / 2;
+    const int n_grp = whole ? 1 : (maxbin <= BK_SORT_CAP - C ? (L + C - 1) / C : 0);
+    auto first_bin_from = [&](int pos) {     // first bin whose start is >= pos (uniform: every thread searches)
+      int lo = 0, hi = nbins;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bins[mid] < pos) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    // one group: bins [b0, b1) = the slice [g0, g0 + Lg) of the bucket's sorted order; `walk` hands over the bucket's keys
+    auto sort_group = [&](int b0, int b1, auto &&walk) {
+      const int g0 = bins[b0], Lg = bins[b1] - g0;
+      walk([&](uint64_t k) {
+        const int bn = bin_fn(k);
+        if (bn >= b0 && bn < b1) sk[atomicAdd(&cur[bn], 1) - g0] = k;
+      });
+      __syncthreads();
+      SORT_STAMP(3);
+      if (by_rank) {
+        // every key's rank inside its bin gives its final position: written straight to the lists (a wave's 64
+        // consecutive keys sit in neighbouring bins, so its stores fall into the same few lines). Ranks first, then
+        // a permutation inside LDS and coalesced stores -- round 4's first version -- holds eight keys and positions
+        // per thread across a barrier: 0.037 vs 0.036 ms at c4, and kept live beside the group loop it cost the second
+        // workgroup per CU (> 64 VGPRs) or spilled (dense scene 0.138 vs 0.118 ms).
+        for (int p = tid; p < Lg; p += BK_THREADS) {
+          const uint64_t k = sk[p];
+          const int bn = bin_fn(k);
+          const int s0 = bins[bn] - g0, e0 = bins[bn + 1] - g0;
+          int rank = 0;
+          for (int j = s0; j < e0; ++j) rank += sk[j] < k ? 1 : 0;
+          put(g0 + s0 + rank, k);
+        }
+        SORT_STAMP(4);
+        SORT_STAMP(5);
+        return;
+      }
+      // many equal depths in one bin: compare-exchange networks instead of ranks
+      if (whole) {      // the round-3 networks on the eight tile segments the split has laid out
+        if (tid < BK_TILES) {
+          seg_start[tid] = bins[tid * NB];
+          seg_cnt[tid] = bins[(tid + 1) * NB] - bins[tid * NB];
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int mxs = 0;
+          for (int q = 0; q < BK_TILES; ++q) mxs = max(mxs, seg_cnt[q]);
+          int np = 1;
+          while (np < mxs) np <<= 1;
+          npad_max_s = np;
+        }
+        __syncthreads();
+        const int grp = tid >> 7;                          // 8 groups of 128 threads
+        bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
+      } else {          // one network over the group (the tile is the top of the key)
+        bk_bitonic<true>(sk, Lg, tid);
       }
       SORT_STAMP(4);
+      for (int t = tid; t < Lg; t += BK_THREADS) put(g0 + t, sk[t]);
       SORT_STAMP(5);
-      return;
-    }
-    // many equal depths in one bin: compare-exchange networks instead of ranks
-    if (whole) {      // the round-3 networks on the eight tile segments the split has laid out
-      if (tid < BK_TILES) {
-        seg_start[tid] = bins[tid * NB];
-        seg_cnt[tid] = bins[(tid + 1) * NB] - bins[tid * NB];
+    };
+    if (in_regs) {       // the whole region fits the sorter: always one group, from the keys the workgroup holds
+      sort_group(0, nbins, resident_keys);
+    } else {
+      for (int g = 0; g < n_grp; ++g) {
+        const int b0 = whole ? 0 : first_bin_from(g * C), b1 = (whole || g + 1 == n_grp) ? nbins : first_bin_from((g + 1) * C);
+        sort_group(b0, b1, stream_keys);
+        if (g + 1 < n_grp) __syncthreads();                // the next group's split overwrites sk
       }
-      __syncthreads();
-      if (tid == 0) {
-        int mxs = 0;
-        for (int q = 0; q < BK_TILES; ++q) mxs = max(mxs, seg_cnt[q]);
-        int np = 1;
-        while (np < mxs) np <<= 1;
-        npad_max_s = np;
-      }
-      __syncthreads();
-      const int grp = tid >> 7;                          // 8 groups of 128 threads
-      bk_bitonic_segments<128>(sk + seg_start[grp], seg_cnt[grp], npad_max_s, tid & 127);
-    } else {          // one network over the group (the tile is the top of the key)
-      bk_bitonic<true>(sk, Lg, tid);
     }
-    SORT_STAMP(4);
-    for (int t = tid; t < Lg; t += BK_THREADS) put(g0 + t, sk[t]);
-    SORT_STAMP(5);
+    if (n_grp == 0) {   // one BIN alone exceeds what a group may hold: one composite-key network in global memory (slow,
+                        // exact); sentinels are the largest key and end up behind the L real ones
+      bk_bitonic<false>(keys + s, LA, tid);
+      for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);
+    }
   };
-  if (in_regs) {       // the whole region fits the sorter: always one group, the keys still in registers (and dead
-                       // afterwards: kept live across the group loop below they cost the second workgroup per CU)
-    sort_group(0, nbins, [&](auto &&f) {
+  const int maxbin1 = histogram(bin1, for_keys);
+  SORT_STAMP(2);
+  // equalise when the ranks would cost (sum n^2 / keys = comparisons per key) well over what balanced bins cost plus
+  // what the extra passes do, about 20 comparisons' worth (a dense scene's long buckets, a dozen keys per bin and 20-30
+  // comparisons per key, lost 30 % to equalising at every long bin)
+  bool equalise = false;
+  if (maxbin1 > BK_BIN_EQ && bscale > 0.f) {
+    float sq = 0.f;
+    for (int i = tid; i < nbins; i += BK_THREADS) sq += (float)bins[i] * (float)bins[i];
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) atomicAdd(&sumsq_s, sq);
+    __syncthreads();
+    // (long buckets: the bins cannot get finer than 120 per tile and every extra pass streams the keys again)
+    equalise = sumsq_s / (float)max(1, Lr) > (in_regs ? 1.5f : 4.f) * (float)Lr / (float)nbins + 24.f;
+  }
+  if (equalise) {
+    // short buckets park their keys in LDS (the sorter's array is free until the split) and read them from there:
+    // with the wider bin function, eight keys in registers across the passes do not fit 64 VGPRs
+    if (in_regs) {
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u) sk[tid + u * BK_THREADS] = kreg[u];
+    }
+    for (int i = tid; i < nbins; i += BK_THREADS) cdf[i] = bins[i];
+    __syncthreads();
+    const int n1 = bk_block_exclusive_scan(cdf, nbins, wave_tot);
+    auto parked_keys = [&](auto &&f) {
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u) {
+        const uint64_t k = sk[tid + u * BK_THREADS];
+        if (k != BK_SENTINEL) f(k);
+      }
+    };
+    auto parked_keys_for_split = [&](auto &&f) {      // (the split writes into the array the keys are parked in)
+      uint64_t kk[BK_KPT];
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u) kk[u] = sk[tid + u * BK_THREADS];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < BK_KPT; ++u)
+        if (kk[u] != BK_SENTINEL) f(kk[u]);
+    };
+    auto mark = [&](uint64_t k) {
+      float t, us;
+      const int d1 = level1(k, t);
+      atomicOr(&occ[(int)(k >> 61) * NB + d1], 1u << sub_of(t, d1, us));
+    };
+    if (in_regs) parked_keys(mark); else stream_keys(mark);
+    for (int i = tid; i < nbins; i += BK_THREADS) bins[i] = 0;
+    if (tid == 0) {
+      cdf[nbins] = n1;
+      maxbin_s = 0;
+    }
+    __syncthreads();
+    const int maxbin2 = in_regs ? histogram(bin2, parked_keys) : histogram(bin2, stream_keys);
+    finish(maxbin2, bin2, parked_keys_for_split);
+  } else {
+    finish(maxbin1, bin1, [&](auto &&f) {      // the keys still in registers (and dead afterwards: kept live across the
+                                               // group loop they cost the second workgroup per CU)
 #pragma unroll
       for (int u = 0; u < BK_KPT; ++u)
         if (kreg[u] != BK_SENTINEL) f(kreg[u]);
     });
-  } else {
-    for (int g = 0; g < n_grp; ++g) {
-      const int b0 = whole ? 0 : first_bin_from(g * C), b1 = (whole || g + 1 == n_grp) ? nbins : first_bin_from((g + 1) * C);
-      sort_group(b0, b1, for_keys);
-      if (g + 1 < n_grp) __syncthreads();                // the next group's split overwrites sk
-    }
-  }
-  if (n_grp == 0) {   // one BIN alone exceeds what a group may hold: one composite-key network in global memory (slow,
-                      // exact); sentinels are the largest key and end up behind the L real ones
-    bk_bitonic<false>(keys + s, LA, tid);
-    for (int t = tid; t < L; t += BK_THREADS) put(t, keys[s + t]);
   }
   if (tid < BK_TILES && bx * BK_TILES + tid < tile_w)
     tile_offsets[row * tile_w + bx * BK_TILES + tid] = min(out_base + bins[tid * NB], capacity);
