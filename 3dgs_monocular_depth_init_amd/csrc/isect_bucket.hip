@@ -548,6 +548,18 @@ __device__ unsigned long long *g_sort_timeline = nullptr;
 #else
 #define SORT_STAMP(k)
 #endif
+#ifdef GSR_SORT_COUNT_PATHS
+// Diagnostic build (tools/build_variants.sh sortpaths "-DGSR_SORT_COUNT_PATHS=1"; tools/sort_paths.py): buckets by the
+// path their sort took: [0] all, [1] equalised bins on keys parked in LDS, [2] equalised bins on streamed keys,
+// [3] more than one group, [4] networks instead of ranks, [5] global-memory network.
+static __device__ unsigned long long g_sort_paths[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SORT_PATH(i)                                                   \
+  do {                                                                 \
+    if (threadIdx.x == 0) atomicAdd(&g_sort_paths[i], 1ull);           \
+  } while (0)
+#else
+#define SORT_PATH(i)
+#endif
 // Pass 3: one workgroup per bucket. The bucket's region holds its listed pairs (and, for tight
 // lists, sentinels in the slots the rectangle rule reserved for dropped pairs); the lists are written
 // COMPACTED: the bucket's output position is the sum of the real counts of the buckets before it.
@@ -754,6 +766,9 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     const bool by_rank = maxbin <= BK_BIN_MAX, whole = L <= BK_SORT_CAP;
     const int C = by_rank ? BK_SORT_CAP - BK_BIN_MAX : BK_SORT_CAP / 2;
     const int n_grp = whole ? 1 : (maxbin <= BK_SORT_CAP - C ? (L + C - 1) / C : 0);
+    if (n_grp > 1) SORT_PATH(3);
+    if (n_grp > 0 && !by_rank) SORT_PATH(4);
+    if (n_grp == 0) SORT_PATH(5);
     auto first_bin_from = [&](int pos) {     // first bin whose start is >= pos (uniform: every thread searches)
       int lo = 0, hi = nbins;
       while (lo < hi) {
@@ -843,7 +858,9 @@ bucket_sort_kernel(int n_buckets, int tile_w, int bw, const int32_t *__restrict_
     // (long buckets: the bins cannot get finer than 120 per tile and every extra pass streams the keys again)
     equalise = sumsq_s / (float)max(1, Lr) > (in_regs ? 1.5f : 4.f) * (float)Lr / (float)nbins + 24.f;
   }
+  SORT_PATH(0);
   if (equalise) {
+    SORT_PATH(in_regs ? 1 : 2);
     // short buckets park their keys in LDS (the sorter's array is free until the split) and read them from there:
     // with the wider bin function, eight keys in registers across the passes do not fit 64 VGPRs
     if (in_regs) {
@@ -912,6 +929,17 @@ static inline int bk_grid(int64_t total, int64_t *chunk) {
 
 }  // namespace gsr
 
+#ifdef GSR_SORT_COUNT_PATHS
+extern "C" int gsr_debug_sort_paths(unsigned long long *out8, int reset) {
+  GSR_CHECK_HIP(hipDeviceSynchronize());
+  GSR_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gsr::g_sort_paths), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_sort_paths), z, sizeof(z)));
+  }
+  return GSR_OK;
+}
+#endif
 #ifdef GSR_SORT_TIMELINE
 extern "C" int gsr_debug_set_sort_timeline(void *buf) {
   unsigned long long *p = (unsigned long long *)buf;

@@ -330,6 +330,41 @@ def test_long_buckets_of_short_tile_lists(R, case):
     _check(cpu, gpu, out_c, out_g, flip_frac=2e-4)
 
 
+@pytest.mark.parametrize("case", ["short_buckets", "long_bucket", "short_buckets_outliers"])
+def test_clustered_depths_take_the_equalised_bins(R, case):
+    """Gaussians on two thin shells (depth 1.4 and 2.6, 0.001 thick): linear depth bins over the bucket's [min, max]
+    would hold a whole shell each, so the sort kernel re-draws its bins from the tiles' own depth distribution
+    (isect_bucket.hip, 'Equalised bins'). The mapping must stay monotone in depth: the lists equal the oracle's full
+    sort. Short buckets (keys parked in LDS), one long bucket (keys streamed, three groups), and shells plus outliers
+    that stretch the range 20x."""
+    g = torch.Generator().manual_seed(17)
+    if case == "long_bucket":
+        N, W, H, box = 18000, 128, 16, (1.8, 0.2, 0.3)
+    else:
+        N, W, H, box = 30000, 256, 64, (3.8, 0.9, 0.3)
+    sc = scenes.make_scene(N, 12, box=box, scale_mean=0.002)
+    shell = torch.where(torch.rand(N, generator=g) < 0.5, -0.6, 0.6)
+    sc["means"][:, 2] = shell + 0.001 * torch.randn(N, generator=g)
+    if case.endswith("outliers"):
+        sc["means"][:60, 2] = -1.5 + 25.0 * torch.rand(60, generator=g)
+    vm = torch.eye(4)[None].clone()
+    vm[0, 2, 3] = 2.0
+    K = torch.tensor([[[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]])
+    dev = {k: v.cuda() for k, v in sc.items()}
+    with torch.no_grad():
+        _, _, mg = R.rasterization(dev["means"], dev["quats"], dev["scales"], dev["opacities"],
+                                   torch.cat([dev["sh0"], dev["shN"]], 1), vm.cuda(), K.cuda(), W, H, sh_degree=1, packed=False)
+    tpg, ids, flat = O.isect_tiles_fast(mg["means2d"].cpu(), mg["radii"].cpu(), mg["depths"].cpu(), 16, W // 16, H // 16)
+    assert torch.equal(mg["flatten_ids"].cpu(), flat)
+    counts = torch.diff(torch.cat([mg["isect_offsets"].reshape(-1).cpu(),
+                                   torch.tensor([flat.numel()], dtype=torch.int32)])).view(H // 16, W // 16)
+    per_bucket = counts.view(H // 16, -1, 8).sum(-1)
+    if case == "long_bucket":
+        assert per_bucket.max().item() > 2 * 8192 and counts.max().item() <= 8192
+    else:
+        assert per_bucket.max().item() <= 8192 and counts.float().mean().item() > 120      # two bins of > 60 keys per tile
+
+
 @pytest.mark.parametrize("tight", [False, True])
 def test_needle_gaussians_tight_lists_vs_oracle(R, tight):
     """Strongly anisotropic, randomly rotated Gaussians (axis ratio 100-300: 2-D conic eigenvalues orders of
