@@ -600,6 +600,8 @@ class _Rasterize(torch.autograd.Function):
             v_opac = v_opac.sum(0) if C > 1 else v_opac.reshape(N)
         if absgrad:
             means2d.absgrad = rows[:, GR_ABS:GR_ABS + 2].view(C, N, 2)
+        if getattr(means2d, "_gsr_keep_grad", False):      # strategy.step_pre_backward asked for it (instead of retain_grad)
+            means2d.grad = v_means2d
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[4]:
             T_final = 1.0 - render_alphas
@@ -793,6 +795,10 @@ def rasterization(
             break
         capacity = None        # rare: this frame outgrew the guess -> rebuild, blocking
 
+    if means2d.requires_grad:
+        # strategy.step_pre_backward may ask the compositing backward to leave `.grad` on this tensor itself (a view into
+        # its gradient rows) instead of registering retain_grad's cloning hook
+        means2d._gsr_grad_in_backward = True
     if render_mode in ("ED", "RGB+ED"):
         render_colors = torch.cat(
             [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)],

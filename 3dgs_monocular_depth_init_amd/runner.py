@@ -415,14 +415,15 @@ def train(
                     raise ValueError("the row exchange renders one view per rank per step (cfg.batch_size = 1)")
                 grad_sync.set_views(torch.stack([trainset[i]["camtoworld"].to(device) for i in everyone]),
                                     torch.stack([trainset[i]["K"].to(device) for i in everyone]))
-            c2w = torch.stack([d["camtoworld"].to(device) for d in data])
-            Ks = torch.stack([d["K"].to(device) for d in data])
-            pixels = torch.stack([d["image"].to(device) for d in data]).float() / 255.0
-            masks = torch.stack([d["mask"].to(device) for d in data]) if "mask" in data[0] else None
+            def batch_of(key):       # the DataLoader's collation; one frame (cfg.batch_size 1) is a view, not a copy launch
+                return data[0][key].to(device)[None] if len(data) == 1 else torch.stack([d[key].to(device) for d in data])
+
+            c2w, Ks = batch_of("camtoworld"), batch_of("K")
+            pixels = batch_of("image").float() / 255.0
+            masks = batch_of("mask") if "mask" in data[0] else None
             extra = {}
             if cfg.depth_loss:                                                         # runner.py:450-452
-                extra = dict(depth_points=torch.stack([d["points"].to(device) for d in data]),
-                             depth_gt=torch.stack([d["depths"].to(device) for d in data]),
+                extra = dict(depth_points=batch_of("points"), depth_gt=batch_of("depths"),
                              depth_lambda=cfg.depth_lambda, scene_scale=scene_scale)
             deg = min(step // max(cfg.sh_degree_interval, 1), cfg.sh_degree)
             if deg != last_deg:

@@ -229,7 +229,13 @@ class DefaultStrategy:
 
     def step_pre_backward(self, params, optimizers, state, step: int, info: Dict[str, Any]) -> None:
         assert self.key_for_gradient in info, "The 2D means of the Gaussians is required but missing."
-        info[self.key_for_gradient].retain_grad()
+        m2d = info[self.key_for_gradient]
+        if getattr(m2d, "_gsr_grad_in_backward", False):
+            # this package's rasterization: its backward leaves `.grad` behind itself, a view into the 64-byte gradient
+            # rows (retain_grad's hook clones the gradient: one strided copy launch per step)
+            m2d._gsr_keep_grad = True
+        else:
+            m2d.retain_grad()
 
     def mutates_params(self, step: int) -> bool:
         """True on the steps whose step_post_backward edits parameters / optimizer state
