@@ -17,6 +17,7 @@ from typing import Dict, Iterable, List
 
 import torch
 import torch.distributed as dist
+from ._lib import current_stream as _raw_stream
 
 PARAM_ORDER = ("shN", "sh0", "means", "quats", "scales", "opacities")
 
@@ -200,7 +201,7 @@ class GatherRowsSync:
             raise RuntimeError("GatherRowsSync.set_views() must be called before every step")
         dev = rows.device
         W = self.world
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         chunks = []
         if self._bufs_n != N:                   # the Gaussian count changed (densification): the old
             self._bufs.clear()                  # generation's buffers (W*N*36 bytes in all) are dropped

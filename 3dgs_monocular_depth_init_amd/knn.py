@@ -14,12 +14,13 @@ import torch
 from torch import Tensor
 
 from ._lib import call, ptr
+from ._lib import current_stream as _raw_stream
 
 BRUTE_FORCE_BELOW = 4096
 
 
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 @torch.no_grad()

@@ -16,6 +16,7 @@ from typing import Dict
 import torch
 
 from ._lib import call
+from ._lib import current_stream as _raw_stream
 
 
 class FusedAdam:
@@ -87,7 +88,7 @@ class FusedAdam:
              PA(*[x[2] for x in pieces]), PA(*[x[3] for x in pieces]),
              (C.c_int64 * n)(*[x[4] for x in pieces]), (C.c_float * n)(*[x[5] for x in pieces]),
              (C.c_float * n)(*[x[6] for x in pieces]), beta1, beta2, eps,
-             torch.cuda.current_stream().cuda_stream)
+             _raw_stream())
 
     @staticmethod
     def pieces_for_range(a: int, b: int, segments):
@@ -306,7 +307,7 @@ class FusedSparseAdam:
             return
         PA = C.c_void_p * n
         call("gsr_sparse_adam_step", n, rows, visible.data_ptr(), PA(*P), PA(*G), PA(*M), PA(*V),
-             (C.c_int32 * n)(*L), (C.c_float * n)(*S), beta1, beta2, eps, torch.cuda.current_stream().cuda_stream)
+             (C.c_int32 * n)(*L), (C.c_float * n)(*S), beta1, beta2, eps, _raw_stream())
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for opt in self.optimizers.values():

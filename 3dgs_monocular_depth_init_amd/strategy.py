@@ -27,6 +27,7 @@ from typing import Any, Callable, Dict, Optional
 import torch
 import torch.distributed as dist
 from torch import Tensor
+from ._lib import current_stream as _raw_stream
 
 
 def _quat_to_rotmat(q: Tensor) -> Tensor:
@@ -131,7 +132,7 @@ def reset_opa(params, optimizers, state: Dict[str, Tensor], value: float) -> Non
         if all(t is None or (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == p.numel()) for t in (m, v)):
             from ._lib import ptr
             _call()("gsr_reset_opacity", p.numel(), ptr(p.detach()), ptr(m), ptr(v), float(max_logit),
-                    torch.cuda.current_stream().cuda_stream)
+                    _raw_stream())
             return
     _update_param_with_optimizer(
         lambda n, p: torch.clamp(p, max=max_logit),
@@ -151,7 +152,7 @@ def _rebuild_by_gather(params, optimizers, M: int, src: Tensor, kind: Tensor,
     from ._lib import ptr
     call = _call()
     dev = src.device
-    st = torch.cuda.current_stream().cuda_stream
+    st = _raw_stream()
     src_m = src if src_m is None else src_m
     kind_m = kind if kind_m is None else kind_m
     N = len(next(iter(params.values())))
@@ -302,7 +303,7 @@ class DefaultStrategy:
             _call()("gsr_strategy_accumulate", C, n, g.data_ptr(), stride, rad.data_ptr(), float(sx),
                     float(sy), state["grad2d"].data_ptr(), state["count"].data_ptr(),
                     rs.data_ptr() if rs is not None else None, max_wh,
-                    torch.cuda.current_stream().cuda_stream)
+                    _raw_stream())
             return
         # host-side formulation (CPU tensors: the unit tests of the schedule and bookkeeping)
         grads = g.clone()
@@ -344,7 +345,7 @@ class DefaultStrategy:
         from ._lib import ptr
         call = _call()
         dev = params["means"].device
-        st = torch.cuda.current_stream().cuda_stream
+        st = _raw_stream()
         N = len(params["means"])
         scene = state["scene_scale"]
         use2d = step < self.refine_scale2d_stop_iter
@@ -495,7 +496,7 @@ def compute_relocation(opacities: Tensor, scales: Tensor, ratios: Tensor, binoms
     new_o, new_s = torch.empty_like(opac), torch.empty_like(sc)
     _call()("gsr_relocation", opac.numel(), opac.data_ptr(), sc.data_ptr(), rat.data_ptr(),
             bn.data_ptr(), n_max, new_o.data_ptr(), new_s.data_ptr(),
-            torch.cuda.current_stream().cuda_stream)
+            _raw_stream())
     return new_o, new_s
 
 
@@ -506,7 +507,7 @@ def inject_noise_to_position(params, optimizers, state, scaler: float,
     noise = torch.randn(means.shape, device=means.device, dtype=means.dtype, generator=generator)
     _call()("gsr_inject_noise", means.shape[0], means.data_ptr(), params["quats"].data_ptr(),
             params["scales"].data_ptr(), params["opacities"].data_ptr(), noise.data_ptr(),
-            float(scaler), torch.cuda.current_stream().cuda_stream)
+            float(scaler), _raw_stream())
 
 
 @torch.no_grad()
