@@ -190,6 +190,43 @@ def test_c5_ranges_sorted_lists_and_linearity(R):
         assert rel < 1e-4, f"{k}: {rel:.2e}"
 
 
+@pytest.mark.parametrize("outliers", [False, True])
+def test_c4_clustered_depths_lists_are_the_full_sort(R, outliers):
+    """The c4 scene with its Gaussians on two thin shells (and, second case, 0.2 % outliers stretching the depth range
+    30x): 850 of the 1020 buckets of the tile-list sort re-draw their depth bins from the tiles' own distribution
+    (isect_bucket.hip 'Equalised bins'; profiles/r04_sort_paths.jsonl). The 2.6 M-entry lists must be exactly the
+    (tile, depth, index) order: compared with a stable sort of the same pairs, element by element."""
+    p = _gpu_scene(1_000_000)
+    g = torch.Generator().manual_seed(11)
+    z = torch.where(torch.rand(1_000_000, generator=g) < 0.5, -0.6, 0.6) + 0.01 * torch.randn(1_000_000, generator=g)
+    if outliers:
+        z[:2000] = -1.0 + 60.0 * torch.rand(2000, generator=g)
+    p["means"] = p["means"].clone()
+    p["means"][:, 2] = z.cuda()
+    vm, K = scenes.cameras([7])
+    with torch.no_grad():
+        _, _, meta = _render(R, p, vm.cuda(), K.cuda())
+    off = meta["isect_offsets"].reshape(-1).long()
+    ids = meta["flatten_ids"].long()
+    assert ids.numel() > 2_000_000
+    tile_of = torch.bucketize(torch.arange(ids.numel(), device=ids.device), off, right=True) - 1
+    depth_bits = meta["depths"].reshape(-1)[ids].view(torch.int32).long()          # positive floats: bit order = value order
+    key = (tile_of << 32 | depth_bits)
+    order = torch.sort(key, stable=True).indices                                   # stable: ties keep list order ...
+    assert torch.equal(order, torch.arange(ids.numel(), device=ids.device))        # ... and the lists are already sorted
+    same = key[1:] == key[:-1]
+    assert (ids[1:][same] > ids[:-1][same]).all()                                   # equal (tile, depth): index order
+    # nothing lost or duplicated: every visible Gaussian is listed once per tile of its rectangle
+    r = meta["radii"][0].float()
+    m2 = meta["means2d"][0]
+    vis = (meta["radii"][0] > 0).all(-1)
+    x0 = ((m2[:, 0] - r[:, 0]) / 16).floor().clamp(0, 120); x1 = ((m2[:, 0] + r[:, 0]) / 16).ceil().clamp(0, 120)
+    y0 = ((m2[:, 1] - r[:, 1]) / 16).floor().clamp(0, 68); y1 = ((m2[:, 1] + r[:, 1]) / 16).ceil().clamp(0, 68)
+    assert int((((x1 - x0) * (y1 - y0))[vis]).sum()) == ids.numel()
+    per_gauss = torch.bincount(ids, minlength=1_000_000)
+    assert torch.equal(per_gauss[vis], ((x1 - x0) * (y1 - y0))[vis].long())
+
+
 def _c2_vs_oracle(width, height, cx, cy, n_gauss=100_000, sh_degree=3, timed_path=False, render_mode="RGB",
                   antialiased=False, img_atol=1e-4):
     """Oracle (CPU, ONE run) against the HIP path on camera 25's window of the 1080p frame.
