@@ -34,7 +34,7 @@ SIGNATURES = {
     "gsr_isect_scan_clear": [_i, _p, _p, _p, _p, _p],
     "gsr_bucket_count": [_i, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _p],
     "gsr_bucket_emit": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p],
-    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p],
+    "gsr_bucket_sort": [_i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i, _p],
     "gsr_pair_masks": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
     "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
@@ -157,11 +157,19 @@ def load():
 # are launched on); read with kernel_times_ms() after a synchronize.
 TIMERS = None
 TIMER_ONLY = None      # optional set of entry-point names to restrict the timing to
+TIMER_EVERY = 1        # bracket every k-th call of a timed entry point only: an event record in front of and behind a
+                       # kernel leaves the GPU idle for ~6 us each (bench.py's timed region samples every 4th step)
+_timer_calls = {}
 
 
 def call(name: str, *args) -> None:
     lib = load()
-    if TIMERS is not None and (TIMER_ONLY is None or name in TIMER_ONLY):
+    timed = TIMERS is not None and (TIMER_ONLY is None or name in TIMER_ONLY)
+    if timed and TIMER_EVERY > 1:
+        k = _timer_calls.get(name, 0)
+        _timer_calls[name] = k + 1
+        timed = k % TIMER_EVERY == 0
+    if timed:
         import torch
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -25,7 +26,7 @@ from torch import Tensor
 
 from . import _lib
 from ._lib import current_stream as _raw_stream
-from ._lib import call, ptr
+from ._lib import GsrastError, call, ptr
 
 TILE = 16
 GRAD_ROW = 16
@@ -449,7 +450,10 @@ class _IsectState:
     count to reach the host (the wait is deferred until after those launches, when the
     GPU has work queued; an overflowing frame is simply rebuilt with larger buffers)."""
     capacity: Dict[int, int] = {}
-    pinned: Dict[int, Tensor] = {}       # one reusable pinned int32[2] per device
+    pinned: Dict[int, Tensor] = {}       # one reusable pinned int32[8] per device
+    pinned_np: Dict[int, object] = {}    # its numpy view (polled by _PendingIsect.resolve)
+    seq: int = 0                         # sequence number of the last frame whose totals were asked for
+    poll_fallbacks: int = 0              # frames whose totals only arrived with a stream synchronisation
     # (device, n_buckets) -> [3, n_buckets] int32: bucket counts | emit cursor | listed pairs. The
     # counts are zero between frames (the sort kernel clears them), the other two rows are cleared
     # by the count kernel: no memset launches
@@ -457,15 +461,39 @@ class _IsectState:
     wg_hist: Dict[Tuple[int, int], Tensor] = {}   # [256, n_buckets]: per-workgroup counts, count pass -> emit pass
 
 
+# How the host learns a frame's totals. True: the sort kernel stores them into pinned host memory followed by the
+# frame's sequence number (system-scope release) and the host polls that word -- no event packet in the queue (an
+# event record between the tile-list kernels and the compositing forward leaves the GPU idle for ~6 us per frame,
+# `profiles/r04c_kernel_stats.csv` traces), and the totals arrive as soon as the last bucket's workgroup is through.
+# False: an event recorded behind the sort, as in rounds 2-4. Polling falls back to a stream synchronisation if the
+# word has not arrived after POLL_DEADLINE_S (pinned memory the device cannot write coherently).
+POLL_TOTALS = os.environ.get("GSR_POLL_TOTALS", "1") == "1"
+POLL_DEADLINE_S = 0.05
+
+
 class _PendingIsect:
-    def __init__(self, dev, n_host, event, capacity):
-        self.dev, self.n_host, self.event, self.capacity = dev, n_host, event, capacity
+    def __init__(self, dev, n_host, event, capacity, seq=0):
+        self.dev, self.n_host, self.event, self.capacity, self.seq = dev, n_host, event, capacity, seq
 
     def resolve(self) -> Tuple[int, bool]:
-        """(n_isects, overflowed). Blocks until the tile-list kernels are done (the compositing
-        forward has been queued behind them by then)."""
-        self.event.synchronize()
-        slots, n = int(self.n_host[0]), int(self.n_host[1])   # reserved slots >= listed pairs
+        """(n_isects, overflowed). Blocks until the tile-list kernels have delivered the frame's totals (the
+        compositing forward has been queued behind them by then)."""
+        if self.event is not None:
+            self.event.synchronize()
+            slots, n = int(self.n_host[0]), int(self.n_host[1])   # reserved slots >= listed pairs
+        else:
+            words = _IsectState.pinned_np[self.dev.index]          # numpy view of n_host: [.., .., slots, pairs, seq]
+            seq, deadline = self.seq, None
+            while int(words[4]) != seq:
+                if deadline is None:
+                    deadline = time.perf_counter() + POLL_DEADLINE_S
+                elif time.perf_counter() > deadline:
+                    torch.cuda.current_stream(self.dev).synchronize()
+                    if int(words[4]) != seq:
+                        raise GsrastError("tile lists: the sort pass never delivered this frame's totals")
+                    _IsectState.poll_fallbacks += 1
+                    break
+            slots, n = int(words[2]), int(words[3])
         _IsectState.capacity[self.dev.index] = int(slots * 1.25) + 8192
         return n, slots > self.capacity
 
@@ -494,7 +522,14 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
     per_cam = int(opacities.dim() == 2)
     n_host = _IsectState.pinned.get(dev.index)
     if n_host is None:
-        n_host = _IsectState.pinned[dev.index] = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        # [0] reserved slots (emit pass), [1] listed pairs (sort pass): read after the event; [2..4] = slots, pairs and
+        # the frame's sequence number, stored by the sort pass for the polling host
+        n_host = _IsectState.pinned[dev.index] = torch.zeros(8, dtype=torch.int32, pin_memory=True)
+        _IsectState.pinned_np[dev.index] = n_host.numpy()
+    poll = POLL_TOTALS and capacity is not None
+    seq = 0
+    if poll:         # (never reused while its predecessor may still sit in the pinned word: strictly increasing, wraps at 2^31)
+        seq = _IsectState.seq = (_IsectState.seq % 0x7fffffff) + 1
     try:
         offsets = torch.empty(n_buckets + 1, dtype=torch.int32, device=dev)
         order = torch.empty(n_buckets, dtype=torch.int32, device=dev)
@@ -520,10 +555,13 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
              ptr(order), None if EXACT_TILE_ORDER else ptr(tile_order), n_host.data_ptr(), ptr(keys), cap, ptr(wg), st)
         call("gsr_bucket_sort", C, tile_w, tile_h, ptr(offsets), ptr(order), ptr(real), ptr(keys),
              ptr(keys_sorted), ptr(flatten_ids), ptr(pair_ids), ptr(tile_offsets),
-             ptr(tile_order) if EXACT_TILE_ORDER else None, cap, ptr(counts), n_host.data_ptr() + 4, st)
-        ev = torch.cuda.Event()
-        ev.record()
-        pending = _PendingIsect(dev, n_host, ev, cap)
+             ptr(tile_order) if EXACT_TILE_ORDER else None, cap, ptr(counts), n_host.data_ptr() + 4,
+             n_host.data_ptr() + 8 if poll else None, seq, st)
+        ev = None
+        if not poll:
+            ev = torch.cuda.Event()
+            ev.record()
+        pending = _PendingIsect(dev, n_host, ev, cap, seq)
     except BaseException:
         _IsectState.scratch.pop(key, None)     # the kernels that clear it may not have run
         raise

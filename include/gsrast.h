@@ -245,7 +245,11 @@ int gsr_bucket_sort(int C, int tile_w, int tile_h, const int32_t *bucket_offsets
                     int64_t capacity /* entries in keys / flatten_ids / pair_ids; offsets are clamped to it */,
                     int32_t *clear_counts /* NULL, or [n_buckets]: zeroed per bucket on the way out
                                              (the count buffer kept across frames) */,
-                    int32_t *total_host /* NULL or host-visible: listed pairs */, void *stream);
+                    int32_t *total_host /* NULL or host-visible: listed pairs */,
+                    int32_t *done_host /* NULL or host-visible coherent int32[3]: [0] reserved slots, [1] listed pairs,
+                                          then [2] = seq stored LAST with system-scope release -- a host may poll [2]
+                                          for this frame's seq instead of waiting on an event */,
+                    int seq, void *stream);
 /* Pair words for lists built by gsr_isect_* / gsr_tile_sort (or by the caller): one launch
  * that evaluates the quadrant mask of every (tile, Gaussian) entry. Needs C*N < 2^28. */
 int gsr_pair_masks(int C, int N, int tile_w, int tile_h, const int32_t *tile_offsets,

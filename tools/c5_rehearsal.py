@@ -185,4 +185,14 @@ rec = {
     "ok": all(math.isfinite(x) for x in losses) and losses[-1] < losses[0],
 }
 print(json.dumps(rec))
+try:        # a counting build of the tile-list sort (tools/sort_paths.py): which path did the buckets of the whole run take?
+    import ctypes
+    lib = importlib.import_module(P + "_lib").load()
+    out = (ctypes.c_ulonglong * 8)()
+    lib.gsr_debug_sort_paths.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    lib.gsr_debug_sort_paths(out, 0)
+    print(json.dumps({"sort_paths": dict(zip(["buckets", "equalised_parked", "equalised_streamed", "several_groups", "networks",
+                                              "global_network"], [int(x) for x in out[:6]]))}))
+except AttributeError:
+    pass
 sys.exit(0 if rec["ok"] else 1)
