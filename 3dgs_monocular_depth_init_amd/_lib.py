@@ -51,6 +51,7 @@ SIGNATURES["gsr_pack_grad_rows"] = [_i64, _p, _p, _p, _p]
 SIGNATURES["gsr_pack_grad_rows_h"] = [_i64, _p, _p, _p, _p]
 SIGNATURES["gsr_project_bwd_adam"] = [_i, _i, _p, _p, _p, _i, _i, _f, _i, _p, _p, _i, _p, _p, _i, _i, _p,
                                       _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
+SIGNATURES["gsr_project_bwd_adam_mcmc"] = SIGNATURES["gsr_project_bwd_adam"][:-1] + [_p, C.c_double, C.c_double, C.c_double, _p]
 SIGNATURES["gsr_project_bwd_rows"] = [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p,
                                       _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p]
 SIGNATURES["gsr_strategy_accumulate"] = [_i, _i, _p, _i, _p, _f, _f, _p, _p, _p, _f, _p]

@@ -24,6 +24,19 @@ struct AdamFused {
   float step_size[AF_COUNT];   // lr / (1 - beta1^t)
   float bc2_sqrt[AF_COUNT];    // sqrt(1 - beta2^t)
   float beta2, eps, omb1, omb2;
+  // What the "mcmc" preset adds to a step (trainer.py:83-92, runner.py:535-545, 649-656), folded into the same pass:
+  // the position noise of MCMCStrategy (gsplat inject_noise_to_position: means += covar . (randn * gate(1 - opacity)
+  // * lr * noise_lr), from the PRE-update parameters, added before the Adam update of the means) and the gradients
+  // of the two regularisers opacity_reg * mean(sigmoid(o)) and scale_reg * mean(exp(s)).
+  const float *noise;          // NULL, or [N,3] standard-normal draws
+  float noise_scale;           // lr(means) * noise_lr
+  float opacity_reg;           // opacity_reg / N        (x sigmoid' = s (1 - s) in the kernel)
+  float scale_reg;             // scale_reg / (3 N)      (x exp(s) in the kernel)
 };
+
+// gate(1 - opacity) * scaler of gsplat's inject_noise_to_position (op_sigmoid with k = 100, x0 = 0.995)
+__device__ __forceinline__ float mcmc_noise_gate(float opacity_act, float scaler) {
+  return 1.0f / (1.0f + expf(-100.0f * ((1.0f - opacity_act) - 0.995f))) * scaler;
+}
 
 }  // namespace gsr

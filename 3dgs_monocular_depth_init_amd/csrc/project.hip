@@ -381,16 +381,31 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     v_op *= o * (1.0f - o);
   }
   if constexpr (FUSE_ADAM) {
-    auto step = [&](int t, int64_t off, float g) {
+    // the mcmc preset's extras (AdamFused, adam_math.h): zero / NULL otherwise
+    float noise_add[3] = {0.f, 0.f, 0.f};
+    if (af.opacity_reg != 0.f || af.scale_reg != 0.f || af.noise) {
+      const float o = opacities_act ? opacities_act[i] : 0.f;
+      v_op += af.opacity_reg * o * (1.0f - o);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v_s[k] += af.scale_reg * s[k];
+      if (af.noise) {
+        const float gate = mcmc_noise_gate(o, af.noise_scale);
+        const float *nz = af.noise + (int64_t)i * 3;
+        const float n0 = nz[0] * gate, n1 = nz[1] * gate, n2 = nz[2] * gate;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) noise_add[r] = covar.m[r][0] * n0 + covar.m[r][1] * n1 + covar.m[r][2] * n2;
+      }
+    }
+    auto step = [&](int t, int64_t off, float g, float add = 0.f) {
       // (plain accesses here: nontemporal DWORD loads / stores of these short rows measured 0.32 -> 0.38 ms)
-      float pp = af.p[t][off], mm = af.m[t][off], vv = af.v[t][off];
+      float pp = af.p[t][off] + add, mm = af.m[t][off], vv = af.v[t][off];
       adam_one(pp, g, mm, vv, af.omb1, af.beta2, af.omb2, af.eps, af.step_size[t], af.bc2_sqrt[t]);
       af.p[t][off] = pp;
       af.m[t][off] = mm;
       af.v[t][off] = vv;
     };
 #pragma unroll
-    for (int k = 0; k < 3; ++k) step(AF_MEANS, (int64_t)i * 3 + k, v_mean[k]);
+    for (int k = 0; k < 3; ++k) step(AF_MEANS, (int64_t)i * 3 + k, v_mean[k], noise_add[k]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) step(AF_QUATS, (int64_t)i * 4 + k, v_q[k]);
 #pragma unroll
@@ -524,8 +539,10 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 #define GSR_PBWD1_WAVES 4   // waves per workgroup of the single-camera kernel (no workgroup-level synchronisation in it)
 #endif
 #ifdef GSR_PBWD1_MIN_BLOCKS
+template <bool EXTRAS>     // EXTRAS: the mcmc preset's position noise and regulariser gradients (AdamFused, adam_math.h)
 __global__ void __launch_bounds__(64 * GSR_PBWD1_WAVES, GSR_PBWD1_MIN_BLOCKS)
 #else
+template <bool EXTRAS>
 __global__ void __launch_bounds__(64 * GSR_PBWD1_WAVES)
 #endif
 project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *__restrict__ K,
@@ -675,6 +692,19 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
         cn[(k - 1) * 3 + 1] = 0.f;
         cn[(k - 1) * 3 + 2] = 0.f;
       }
+  }
+  if constexpr (EXTRAS) {
+    v_op += af.opacity_reg * o_act * (1.0f - o_act);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_s[k] += af.scale_reg * s[k];
+    if (af.noise) {      // every Gaussian, visible or not, from the pre-update quats / scales / opacity
+      const gs::Mat3 cov = gs::quat_scale_to_covar(q, s);
+      const float gate = mcmc_noise_gate(o_act, af.noise_scale);
+      const float *nz = af.noise + (int64_t)i * 3;
+      const float n0 = nz[0] * gate, n1 = nz[1] * gate, n2 = nz[2] * gate;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) mean[r] += cov.m[r][0] * n0 + cov.m[r][1] * n1 + cov.m[r][2] * n2;
+    }
   }
   // Adam on the short rows: parameters from the registers loaded at the top, moments prefetched
   {
@@ -954,16 +984,17 @@ extern "C" int gsr_pack_grad_rows(int64_t n, const float *grad_rows, const int32
 // Optimizer in backward: gsr_project_bwd and gsr_adam_step in one pass. The six parameter
 // tensors (means, quats, raw scales, raw opacities, sh0 [N,1,3], shN [N,15,3]) are updated
 // in place from the gradients this backward produces; no gradient tensor is written.
-extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks,
-                                    const float *campos, int width, int height, float eps2d,
-                                    int sh_degree, const int32_t *radii, const float *grad_rows,
-                                    int grad_stride, const float *v_depths,
-                                    const float *v_compensations,
-                                    int depth_channel, int activations, const float *opacities_act,
-                                    void *const *params, void *const *exp_avg,
-                                    void *const *exp_avg_sq, const float *step_size,
-                                    const float *bc2_sqrt, double beta1_d, double beta2_d,
-                                    double eps_d, void *stream) {
+static int project_bwd_adam_impl(int C, int N, const float *viewmats, const float *Ks,
+                                 const float *campos, int width, int height, float eps2d,
+                                 int sh_degree, const int32_t *radii, const float *grad_rows,
+                                 int grad_stride, const float *v_depths,
+                                 const float *v_compensations,
+                                 int depth_channel, int activations, const float *opacities_act,
+                                 void *const *params, void *const *exp_avg,
+                                 void *const *exp_avg_sq, const float *step_size,
+                                 const float *bc2_sqrt, double beta1_d, double beta2_d,
+                                 double eps_d, const float *noise, float noise_scale, float opacity_reg,
+                                 float scale_reg, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd_adam: bad sizes");
   if (N == 0) return GSR_OK;
   GSR_REQUIRE(viewmats && Ks && campos && grad_rows && params && exp_avg && exp_avg_sq &&
@@ -990,6 +1021,11 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
   af.eps = (float)eps_d;
   af.omb1 = (float)(1.0 - beta1_d);
   af.omb2 = (float)(1.0 - beta2_d);
+  af.noise = noise;
+  af.noise_scale = noise_scale;
+  af.opacity_reg = opacity_reg / (float)N;
+  af.scale_reg = scale_reg / (3.0f * (float)N);
+  const bool extras = noise != nullptr || opacity_reg != 0.f || scale_reg != 0.f;
   // One camera, fp32 scratch rows, 16-byte aligned shN blocks: the whole waves go to the single-camera
   // kernel, a last partial wave (N % 64 Gaussians) to the generic one.
   int n_fast = 0;
@@ -1000,10 +1036,15 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
     n_fast = N & ~63;
 #endif
   if (n_fast > 0) {
-    hipLaunchKernelGGL(gsr::project_bwd_adam1_kernel, dim3((unsigned)gsr::ceil_div(n_fast, 64 * GSR_PBWD1_WAVES)),
-                       dim3(64 * GSR_PBWD1_WAVES), 0,
-                       (hipStream_t)stream, n_fast, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii,
-                       grad_rows, v_depths, v_compensations, depth_channel, opacities_act, af);
+    const dim3 grid((unsigned)gsr::ceil_div(n_fast, 64 * GSR_PBWD1_WAVES)), block(64 * GSR_PBWD1_WAVES);
+    if (extras)
+      hipLaunchKernelGGL(gsr::project_bwd_adam1_kernel<true>, grid, block, 0, (hipStream_t)stream, n_fast, viewmats, Ks,
+                         campos, width, height, eps2d, sh_degree, radii, grad_rows, v_depths, v_compensations,
+                         depth_channel, opacities_act, af);
+    else
+      hipLaunchKernelGGL(gsr::project_bwd_adam1_kernel<false>, grid, block, 0, (hipStream_t)stream, n_fast, viewmats, Ks,
+                         campos, width, height, eps2d, sh_degree, radii, grad_rows, v_depths, v_compensations,
+                         depth_channel, opacities_act, af);
     GSR_CHECK_LAUNCH("project_bwd_adam (single camera)");
   }
   const int n_rest = N - n_fast;
@@ -1016,6 +1057,7 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
       at.m[t] += a0 * row_floats[t];
       at.v[t] += a0 * row_floats[t];
     }
+    if (at.noise) at.noise += a0 * 3;
     // (with n_fast > 0 this is C == 1: per-Gaussian arrays simply start a0 rows later)
     hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, dim3((unsigned)gsr::ceil_div(n_rest, 256)), dim3(256), 0,
                        (hipStream_t)stream, C, n_rest, at.p[gsr::AF_MEANS], at.p[gsr::AF_QUATS],
@@ -1027,4 +1069,40 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
     GSR_CHECK_LAUNCH("project_bwd_adam");
   }
   return GSR_OK;
+}
+
+extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks,
+                                    const float *campos, int width, int height, float eps2d,
+                                    int sh_degree, const int32_t *radii, const float *grad_rows,
+                                    int grad_stride, const float *v_depths,
+                                    const float *v_compensations,
+                                    int depth_channel, int activations, const float *opacities_act,
+                                    void *const *params, void *const *exp_avg,
+                                    void *const *exp_avg_sq, const float *step_size,
+                                    const float *bc2_sqrt, double beta1_d, double beta2_d,
+                                    double eps_d, void *stream) {
+  return project_bwd_adam_impl(C, N, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii, grad_rows,
+                               grad_stride, v_depths, v_compensations, depth_channel, activations, opacities_act,
+                               params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1_d, beta2_d, eps_d, nullptr,
+                               0.f, 0.f, 0.f, stream);
+}
+
+// The same pass with what the "mcmc" preset adds to a step (see AdamFused in adam_math.h): position noise from
+// `noise` [N,3] (NULL: none) scaled by noise_scale = lr(means) * noise_lr, and the gradients of
+// opacity_reg * mean(sigmoid(opacities)) + scale_reg * mean(exp(scales)).
+extern "C" int gsr_project_bwd_adam_mcmc(int C, int N, const float *viewmats, const float *Ks,
+                                         const float *campos, int width, int height, float eps2d,
+                                         int sh_degree, const int32_t *radii, const float *grad_rows,
+                                         int grad_stride, const float *v_depths,
+                                         const float *v_compensations,
+                                         int depth_channel, int activations, const float *opacities_act,
+                                         void *const *params, void *const *exp_avg,
+                                         void *const *exp_avg_sq, const float *step_size,
+                                         const float *bc2_sqrt, double beta1_d, double beta2_d,
+                                         double eps_d, const float *noise, double noise_scale,
+                                         double opacity_reg, double scale_reg, void *stream) {
+  return project_bwd_adam_impl(C, N, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii, grad_rows,
+                               grad_stride, v_depths, v_compensations, depth_channel, activations, opacities_act,
+                               params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1_d, beta2_d, eps_d, noise,
+                               (float)noise_scale, (float)opacity_reg, (float)scale_reg, stream);
 }

@@ -150,6 +150,16 @@ class FusedAdam:
 
     # ---- optimizer in backward ------------------------------------------------------
     FUSED_ORDER = ("means", "quats", "scales", "opacities", "sh0", "shN")
+    # What the "mcmc" preset adds to ONE step, applied inside the fused backward (gsr_project_bwd_adam_mcmc): set by
+    # runner.train_step before loss.backward(), consumed (and cleared) by the projection backward.
+    step_extras = None      # (noise [N,3] or None, noise_scale, opacity_reg, scale_reg)
+
+    def set_step_extras(self, noise, noise_scale: float, opacity_reg: float, scale_reg: float) -> None:
+        self.step_extras = (noise, float(noise_scale), float(opacity_reg), float(scale_reg))
+
+    def take_step_extras(self):
+        ex, self.step_extras = self.step_extras, None
+        return ex
 
     def fuse_into_backward(self, enable: bool = True) -> None:
         """Single-process training with a purely photometric loss: let the projection

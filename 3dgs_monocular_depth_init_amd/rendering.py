@@ -251,6 +251,9 @@ class _ProjectSH(torch.autograd.Function):
             if args is not None:
                 P, M, V, ss, bc2, beta1, beta2, eps = args
                 if chunks is not None:
+                    if getattr(bo, "step_extras", None) is not None:
+                        raise NotImplementedError("row exchange: the mcmc step extras are single-rank (runner.train_step keeps "
+                                                  "the reference's order on view-parallel ranks)")
                     PA = type(P)
                     # bytes per Gaussian of means, quats, scales, opacities, sh0, shN
                     row_bytes = (12, 16, 12, 4, 12, 180)
@@ -262,10 +265,18 @@ class _ProjectSH(torch.autograd.Function):
                              None, -1, activations, opac_act.data_ptr() + 4 * a0, off(P), off(M),
                              off(V), ss, bc2, beta1, beta2, eps, _stream())
                     return (None,) * 10
-                call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
-                     height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
-                     ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
-                     beta1, beta2, eps, _stream())
+                extras = bo.take_step_extras() if hasattr(bo, "take_step_extras") else None
+                if extras is not None:       # the "mcmc" preset: position noise + regulariser gradients in the same pass
+                    noise, noise_scale, opacity_reg, scale_reg = extras
+                    call("gsr_project_bwd_adam_mcmc", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
+                         height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
+                         ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
+                         beta1, beta2, eps, ptr(noise), noise_scale, opacity_reg, scale_reg, _stream())
+                else:
+                    call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
+                         height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
+                         ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
+                         beta1, beta2, eps, _stream())
                 return (None,) * 10
         if chunks is not None:
             # gathered rows, optimizer NOT fused (a step on which the strategy must see the

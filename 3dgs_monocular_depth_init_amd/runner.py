@@ -196,27 +196,51 @@ def train_step(
         d = d.squeeze(3).squeeze(1)
         disp = torch.where(d > 0.0, 1.0 / d, torch.zeros_like(d))       # loss in disparity space
         loss = loss + F.l1_loss(disp, 1.0 / depth_gt) * scene_scale * depth_lambda
-    if opacity_reg > 0.0:                                                # runner.py:535-539
-        loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
-    if scale_reg > 0.0:                                                  # runner.py:540-545
-        loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
     from . import rendering as _R
     from .losses import unit_gradient
+    from .strategy import MCMCStrategy
     fused = _R._BACKWARD_OPTIMIZER
+    regs = opacity_reg > 0.0 or scale_reg > 0.0
+    # The fused backward can take the "mcmc" preset's extras along (optim.FusedAdam.set_step_extras ->
+    # gsr_project_bwd_adam_mcmc): the regularisers' gradients, and MCMCStrategy's position noise on the steps between
+    # refinements -- computed from the pre-update parameters and added before the Adam update, i.e. the reference's
+    # strategy-then-optimizer order (runner.py:649-679). Single rank only.
+    extras_ok = fused is not None and hasattr(fused, "set_step_extras") and grad_sync is None
+    mcmc_noise = (extras_ok and isinstance(strategy, MCMCStrategy) and not strategy.refines(step)
+                  and before_update is None)
     # reference order on the steps where the strategy edits parameters: backward -> strategy ->
     # optimizer (runner.py:638-679); the fused update would land before the strategy
-    ordered = fused is not None and ((strategy is not None and strategy.mutates_params(step))
+    ordered = fused is not None and ((strategy is not None and strategy.mutates_params(step) and not mcmc_noise)
                                      or before_update is not None)
-    if fused is not None and not ordered and (opacity_reg > 0.0 or scale_reg > 0.0):
-        # (on `ordered` steps -- every step of MCMCStrategy, whose preset uses both regularisers --
-        # the fusion is suspended: the regularisers' gradients accumulate into .grad next to the
-        # rasterizer's, identically on all ranks, and the optimizer steps once, afterwards)
+    use_extras = extras_ok and not ordered and (regs or mcmc_noise)
+    reg_value = None
+    if regs and use_extras:             # their gradients come from the fused backward; the VALUE still belongs to the loss
+        with torch.no_grad():
+            reg_value = 0.0
+            if opacity_reg > 0.0:
+                reg_value = reg_value + opacity_reg * torch.sigmoid(splats["opacities"]).mean()
+            if scale_reg > 0.0:
+                reg_value = reg_value + scale_reg * torch.exp(splats["scales"]).mean()
+    else:
+        if opacity_reg > 0.0:                                                # runner.py:535-539
+            loss = loss + opacity_reg * torch.abs(torch.sigmoid(splats["opacities"])).mean()
+        if scale_reg > 0.0:                                                  # runner.py:540-545
+            loss = loss + scale_reg * torch.abs(torch.exp(splats["scales"])).mean()
+    if fused is not None and not ordered and regs and not use_extras:
+        # (on `ordered` steps the fusion is suspended: the regularisers' gradients accumulate into .grad next
+        # to the rasterizer's, identically on all ranks, and the optimizer steps once, afterwards)
         raise RuntimeError(
             "train_step: opacity_reg / scale_reg reach the parameters outside the rasterizer; "
-            "optimizer-in-backward (FusedAdam.fuse_into_backward, GatherRowsSync) would apply them "
+            "optimizer-in-backward under a row exchange (GatherRowsSync) would apply them "
             "in a second Adam step. Disable the fusion for this preset.")
     if ordered:
         _R.set_backward_optimizer(None)
+    if use_extras:
+        noise, noise_scale = None, 0.0
+        if mcmc_noise:
+            noise = strategy.draw_noise(splats, strategy_state)
+            noise_scale = optimizers["means"].param_groups[0]["lr"] * strategy.noise_lr
+        fused.set_step_extras(noise, noise_scale, opacity_reg, scale_reg)
     try:
         one = unit_gradient(loss.device)
         loss.backward(one if one.dtype == loss.dtype else None)          # runner.py:547 (root
@@ -224,15 +248,20 @@ def train_step(
     finally:
         if ordered:
             _R.set_backward_optimizer(fused)
+    if use_extras and fused.take_step_extras() is not None:
+        raise RuntimeError("train_step: the projection backward did not take the fused update (and with it the step's "
+                           "noise / regulariser gradients); disable fuse_into_backward for this configuration")
+    if reg_value is not None:
+        loss = loss.detach() + reg_value
     if grad_sync is not None:
         grad_sync()
     if before_update is not None:
         before_update(loss.detach(), info)
     if strategy is not None:                                             # runner.py:639-658
-        from .strategy import MCMCStrategy
         if isinstance(strategy, MCMCStrategy):
             means_lr = optimizers["means"].param_groups[0]["lr"]        # schedulers[0].get_last_lr()[0]
-            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, lr=means_lr)
+            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, lr=means_lr,
+                                        noise_done=mcmc_noise)
         else:
             strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
     if optimizers is not None:
@@ -370,7 +399,8 @@ def train(
             opt = FusedAdam(optimizers)
             if grad_sync is not None and hasattr(grad_sync, "attach"):
                 grad_sync.attach(opt)
-            elif grad_sync is None and world_size == 1 and not regs and _R._BACKWARD_OPTIMIZER is None:
+            elif grad_sync is None and world_size == 1 and _R._BACKWARD_OPTIMIZER is None:
+                # (the regularisers' gradients and MCMCStrategy's noise travel with the fused backward: train_step)
                 opt.fuse_into_backward(True)
                 fused_here = True
     means_opt = opt["means"]

@@ -650,23 +650,38 @@ class MCMCStrategy:
             state["generator"] = g
         return state["generator"]
 
+    def refines(self, step: int) -> bool:
+        return self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0
+
     def mutates_params(self, step: int) -> bool:
         """Position noise is injected on every step, computed from the pre-update parameters
-        (runner.py:649-656 before 676-679): never compatible with optimizer-in-backward."""
+        (runner.py:649-656 before 676-679): not compatible with the plain optimizer-in-backward.
+        (Between refine steps `runner.train_step` hands the noise to the fused backward instead --
+        `draw_noise` + `FusedAdam.set_step_extras` -- which applies it in the reference's order.)"""
         return True
 
-    def step_post_backward(self, params, optimizers, state, step: int, info, lr: float, **_) -> None:
+    def draw_noise(self, params, state) -> Tensor:
+        """The standard-normal draws of this step's position noise, from the strategy's generator (the same draw
+        `step_post_backward` -> `inject_noise_to_position` makes: on a step without relocation / addition it is the
+        only one, so the generator's sequence is the same either way)."""
+        means = params["means"]
+        return torch.randn(means.shape, device=means.device, dtype=means.dtype, generator=self._generator(state, means.device))
+
+    def step_post_backward(self, params, optimizers, state, step: int, info, lr: float, noise_done: bool = False,
+                           **_) -> None:
         dev = params["means"].device
         if state["binoms"].device != dev:
             state["binoms"] = state["binoms"].to(dev)
         binoms, gen = state["binoms"], self._generator(state, dev)
-        if self.refine_start_iter < step < self.refine_stop_iter and step % self.refine_every == 0:
+        if self.refines(step):
+            assert not noise_done, "the fused noise is for the steps between refinements"
             n_rel = self._relocate_gs(params, optimizers, binoms, gen)
             n_new = self._add_new_gs(params, optimizers, binoms, gen)
             if self.verbose:
                 print(f"Step {step}: Relocated {n_rel} GSs. Added {n_new} GSs. "
                       f"Now having {len(params['means'])} GSs.")
-        inject_noise_to_position(params, optimizers, {}, scaler=lr * self.noise_lr, generator=gen)
+        if not noise_done:
+            inject_noise_to_position(params, optimizers, {}, scaler=lr * self.noise_lr, generator=gen)
 
     def _relocate_gs(self, params, optimizers, binoms, gen) -> int:
         dead = torch.sigmoid(params["opacities"].flatten()) <= self.min_opacity

@@ -154,6 +154,20 @@ int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks, c
                          const float *opacities_act, void *const *params, void *const *exp_avg,
                          void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
                          double beta1, double beta2, double eps, void *stream);
+/* The same pass with what the reference's "mcmc" preset adds to every step (trainer.py:83-92): the position
+ * noise of gsplat's MCMCStrategy.step_post_backward -> inject_noise_to_position (runner.py:649-656; means +=
+ * covar . (noise * gate(1 - opacity) * noise_scale), from the PRE-update parameters, applied before the Adam
+ * update of the means as in the reference's strategy-then-optimizer order) and the gradients of the two
+ * regularisers opacity_reg * mean(sigmoid(opacities)) + scale_reg * mean(exp(scales)) (runner.py:535-545).
+ * noise: [N,3] standard-normal draws or NULL; noise_scale = lr(means) * noise_lr. */
+int gsr_project_bwd_adam_mcmc(int C, int N, const float *viewmats, const float *Ks, const float *campos,
+                              int width, int height, float eps2d, int sh_degree, const int32_t *radii,
+                              const float *grad_rows, int grad_stride, const float *v_depths,
+                              const float *v_compensations, int depth_channel, int activations,
+                              const float *opacities_act, void *const *params, void *const *exp_avg,
+                              void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
+                              double beta1, double beta2, double eps, const float *noise, double noise_scale,
+                              double opacity_reg, double scale_reg, void *stream);
 
 /* ---------------------------------------------------------------------------
  * A5: per-tile depth-sorted intersection lists.

@@ -151,3 +151,69 @@ def test_gather_launch_paths_equal_the_tensor_ops(op, monkeypatch):
         assert len(b["means"]) == n + 450 and float(b["means.m"][n:].abs().max()) == 0.0
     if op == "reset_opa":
         assert float(b["opacities"].max()) <= math.log(0.01 / 0.99) + 1e-6 and float(b["opacities.v"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N", [2000, 2043])      # whole waves only / a 59-Gaussian tail through the generic kernel
+def test_mcmc_step_fused_into_backward_equals_reference_order(N):
+    """The "mcmc" preset's step with the optimizer in the backward (gsr_project_bwd_adam_mcmc: Adam + the position
+    noise from the pre-update parameters + the gradients of the opacity / scale regularisers in ONE pass) against the
+    reference's order -- backward, regularisers through autograd, strategy.step_post_backward (noise), optimizer.step
+    (runner.py:535-547, 649-679) -- on two copies of a scene, same noise generator seed, across refine steps (which
+    take the reference order on both sides). Same loss values, same parameters and moments to rounding."""
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    sc = scenes.make_scene(N, 4, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 20, 40, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).cuda(), K.cuda()
+    target = torch.rand(4, H, W, 3, generator=torch.Generator().manual_seed(5)).cuda()
+
+    logit_op = torch.logit(sc["opacities"])
+    logit_op[:300] = math.log(0.01 / 0.99)        # nearly transparent: the noise gate is 0.38 there (1e-22 at opacity 0.5)
+    logit_op[300:340] = -8.0                      # dead: relocated on the refine steps
+
+    def world(fuse):
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)),
+            torch.log(sc["scales"]), quats=sc["quats"], opacities_logit=logit_op.clone(), shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        fused.fuse_into_backward(fuse)
+        strat = S().MCMCStrategy(cap_max=N, refine_start_iter=2, refine_every=5, refine_stop_iter=100, noise_lr=5e4)
+        return splats, fused, strat, strat.initialize_state()
+
+    calls = []
+    L = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+    real_call = L.call
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+
+    def spy(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+
+    out = {}
+    for fuse in (True, False):
+        splats, fused, strat, state = world(fuse)
+        losses = []
+        R.call = spy
+        try:
+            for step in range(1, 13):
+                k = step % 4
+                loss, _ = runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target[k:k + 1], step=step,
+                                            strategy=strat, strategy_state=state, opacity_reg=0.01, scale_reg=0.01)
+                losses.append(float(loss))
+        finally:
+            R.call = real_call
+            fused.fuse_into_backward(False)
+        out[fuse] = (losses, {k: v.detach().clone() for k, v in splats.items()},
+                     {k: fused[k].state[splats[k]]["exp_avg_sq"].clone() for k in splats})
+        if fuse:
+            assert calls.count("gsr_project_bwd_adam_mcmc") == 10        # every step but the two refine steps (5, 10)
+            calls.clear()
+    (l1, p1, v1), (l0, p0, v0) = out[True], out[False]
+    assert max(abs(a - b) for a, b in zip(l1, l0)) < 1e-6
+    moved = (p0["means"].cpu() - sc["means"])[:300].abs().max()
+    assert moved > 5e-3                                                   # the noise is far above the tolerance below
+    for k in p0:
+        scale = float(p0[k].abs().max())
+        assert float((p1[k] - p0[k]).abs().max()) <= 2e-5 * scale + 1e-7, k
+        assert float((v1[k] - v0[k]).abs().max()) <= 1e-4 * float(v0[k].abs().max()) + 1e-12, k

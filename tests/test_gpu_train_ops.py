@@ -376,7 +376,8 @@ def test_fused_backward_with_strategy_keeps_reference_order():
 def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
     """the MCMC preset's opacity / scale regularisers reach the parameters
     outside the rasterizer; with optimizer-in-backward they used to be applied in a SECOND Adam
-    step. train_step now raises, and FusedAdam.step() raises on any stray gradient."""
+    step. Since round 4 `train_step` hands them to the fused backward (gsr_project_bwd_adam_mcmc; same
+    parameters as the autograd route, checked here), and FusedAdam.step() still raises on any stray gradient."""
     from tests import scenes
     runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
     optim = importlib.import_module("3dgs_monocular_depth_init_amd.optim")
@@ -392,8 +393,20 @@ def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
     fused = optim.FusedAdam(opts)
     fused.fuse_into_backward(True)
     try:
-        with pytest.raises(RuntimeError, match="opacity_reg"):
-            runner.train_step(splats, fused, c2w, K, target, step=5000, opacity_reg=0.01)
+        # the regularisers through the fused backward == through autograd + a separate Adam step
+        splats_b, opts_b = runner.create_splats_with_optimizers(
+            sc["means"], splats["sh0"].detach().cpu()[:, 0, :] * 0.28209479177387814 + 0.5, torch.log(sc["scales"]), quats=sc["quats"])
+        with torch.no_grad():
+            for k in splats:
+                splats_b[k].copy_(splats[k])
+        fused_b = optim.FusedAdam(opts_b)
+        la, _ = runner.train_step(splats, fused, c2w, K, target, step=5000, opacity_reg=0.01, scale_reg=0.02)
+        R.set_backward_optimizer(None)
+        lb, _ = runner.train_step(splats_b, fused_b, c2w, K, target, step=5000, opacity_reg=0.01, scale_reg=0.02)
+        R.set_backward_optimizer(fused)
+        assert abs(float(la) - float(lb)) < 1e-6
+        for k in splats:
+            assert float((splats[k] - splats_b[k]).detach().abs().max()) <= 1e-6 * float(splats_b[k].detach().abs().max()) + 1e-8, k
         # a loss term added by hand
         renders, _, _ = runner.rasterize_splats(splats, c2w, K, W, H, sh_degree=3)
         loss = (renders - target).abs().mean() + 0.01 * torch.sigmoid(splats["opacities"]).mean()
@@ -403,7 +416,7 @@ def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
         fused.zero_grad()
         # and the plain fused step still works afterwards
         runner.train_step(splats, fused, c2w, K, target, step=5000)
-        assert float(fused["means"].state[splats["means"]]["step"]) == 2.0
+        assert float(fused["means"].state[splats["means"]]["step"]) == 3.0
     finally:
         R.set_backward_optimizer(None)
 
