@@ -292,20 +292,29 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
     const int gx = x0 + lane;                               // this lane's output column
     const int gxa = x0 - SSIM_R + lane, gxb = x0 + SS_COLS - SSIM_R + lane;   // columns it stages (b: lanes 0..9)
     const float *p1 = img1 + n * v1.sn + c * v1.sc, *p2 = img2 + n * v2.sn + c * v2.sc;
-    auto fetch = [&](int j, float &xa, float &ya, float &xb, float &yb) {   // input row j of the strip
+    // running pointers of the row being fetched (one 64-bit add per row instead of four 64-bit multiply-adds)
+    const float *r1a = p1 + (int64_t)(y0 - SSIM_R) * v1.sh + (int64_t)gxa * v1.sw, *r1b = r1a + (int64_t)SS_COLS * v1.sw;
+    const float *r2a = p2 + (int64_t)(y0 - SSIM_R) * v2.sh + (int64_t)gxa * v2.sw, *r2b = r2a + (int64_t)SS_COLS * v2.sw;
+    const bool col_a = gxa >= 0 && gxa < W, col_b = lane < 2 * SSIM_R && gxb < W;
+    auto fetch = [&](int j, float &xa, float &ya, float &xb, float &yb) {   // input row j of the strip (called for j = 0, 1, 2, ...)
       const int gy = y0 - SSIM_R + j;
       xa = ya = xb = yb = 0.f;
       if (gy >= 0 && gy < H) {
-        if (gxa >= 0 && gxa < W) {
-          xa = p1[gy * v1.sh + gxa * v1.sw];
-          ya = p2[gy * v2.sh + gxa * v2.sw];
+        if (col_a) {
+          xa = *r1a;
+          ya = *r2a;
         }
-        if (lane < 2 * SSIM_R && gxb < W) {
-          xb = p1[gy * v1.sh + gxb * v1.sw];
-          yb = p2[gy * v2.sh + gxb * v2.sw];
+        if (col_b) {
+          xb = *r1b;
+          yb = *r2b;
         }
       }
+      r1a += v1.sh;
+      r1b += v1.sh;
+      r2a += v2.sh;
+      r2b += v2.sh;
     };
+    const int64_t o_first = ((int64_t)plane * H + y0) * W + gx;   // this lane's element of the strip's first output row
     float wm1[11], wm2[11], w11[11], w22[11], w12[11];      // horizontally filtered rows: x, y, xx, yy, xy
     float nxa, nya, nxb, nyb;
     fetch(0, nxa, nya, nxb, nyb);
@@ -345,6 +354,7 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
           w12[sl] = sym11(t);
           if (j >= 2 * SSIM_R) {                            // output row i = j - 10: window rows j-10 .. j
             const int i = j - 2 * SSIM_R, gy = y0 + i;
+            const int64_t o_row = o_first + (int64_t)i * W;
             float o1[11], o2[11], o11[11], o22[11], o12[11];
 #pragma unroll
             for (int k = 0; k < 11; ++k) {                  // slot of input row (j - 10 + k)
@@ -360,16 +370,19 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
               const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
               const float A = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B = s1 + s2 + SSIM_C2;
               const float Cc = 2.f * mu1 * mu2 + SSIM_C1, D = 2.f * s12 + SSIM_C2;
-              const float iAB = 1.0f / (A * B);
+              // (two v_rcp_f32 instead of four IEEE divisions: 44 of this loop's 278 VALU instructions per row went
+              // into the division sequences; A >= C1 and B >= C2 are far from the denormal range)
+              const float iA = __builtin_amdgcn_rcpf(A), iB = __builtin_amdgcn_rcpf(B);
+              const float iAB = iA * iB;
               const float m = Cc * D * iAB;
               const bool counted = !valid_only || (gx >= SSIM_R && gx < W - SSIM_R && gy >= SSIM_R && gy < H - SSIM_R);
               if (counted) acc_ssim += m;
               if (dm_mu1) {
-                const int64_t o = ((int64_t)plane * H + gy) * W + gx;
+                const int64_t o = o_row;
                 const float w = counted ? 1.f : 0.f;   // cropped pixels get no gradient
-                dm_mu1[o] = w * (2.f * mu2 * D * iAB - 2.f * mu2 * Cc * iAB - 2.f * mu1 * Cc * D * iAB / A +
-                                 2.f * mu1 * Cc * D * iAB / B);
-                dm_s1[o] = w * (-Cc * D * iAB / B);
+                dm_mu1[o] = w * (2.f * mu2 * D * iAB - 2.f * mu2 * Cc * iAB - 2.f * mu1 * m * iA +
+                                 2.f * mu1 * m * iB);
+                dm_s1[o] = w * (-m * iB);
                 dm_s12[o] = w * (2.f * Cc * iAB);
               }
             }
@@ -416,24 +429,32 @@ ssim_bwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
   const float up = upstream ? upstream[0] : 1.0f;
   const float w_ssim = weights ? weights[0] : up * scale_ssim;
   const float w_l1 = weights ? weights[1] : up * scale_l1;
-  const int64_t pbase = (int64_t)plane * H * W;
-  auto fetch = [&](int j, float a[2], float b[2], float d[2]) {
+  // running offsets / pointers (one add per row each instead of 64-bit multiply-adds per access)
+  const bool col_a = gxa >= 0 && gxa < W, col_b = lane < 2 * SSIM_R && gxb < W;
+  int64_t ro = (int64_t)plane * H * W + (int64_t)(y0 - SSIM_R) * W;      // map row being fetched
+  auto fetch = [&](int j, float a[2], float b[2], float d[2]) {           // (called for j = 0, 1, 2, ...)
     const int gy = y0 - SSIM_R + j;
     a[0] = a[1] = b[0] = b[1] = d[0] = d[1] = 0.f;
     if (gy >= 0 && gy < H) {
-      const int64_t ro = pbase + (int64_t)gy * W;
-      if (gxa >= 0 && gxa < W) {
+      if (col_a) {
         a[0] = dm_mu1[ro + gxa];
         b[0] = dm_s1[ro + gxa];
         d[0] = dm_s12[ro + gxa];
       }
-      if (lane < 2 * SSIM_R && gxb < W) {
+      if (col_b) {
         a[1] = dm_mu1[ro + gxb];
         b[1] = dm_s1[ro + gxb];
         d[1] = dm_s12[ro + gxb];
       }
     }
+    ro += W;
   };
+  // the images' own pixel of the NEXT output row travels with the next map row (it was loaded at its use: a global
+  // round trip per row in the wave's dependent chain)
+  const float *px = img1 + n * v1.sn + c * v1.sc + (int64_t)y0 * v1.sh + (int64_t)gx * v1.sw;
+  const float *py = img2 + n * v2.sn + c * v2.sc + (int64_t)y0 * v2.sh + (int64_t)gx * v2.sw;
+  float *pg = grad + n * vg.sn + c * vg.sc + (int64_t)y0 * vg.sh + (int64_t)gx * vg.sw;
+  float x_next = 0.f, y_next = 0.f;
   float wa[11], wb[11], wd[11];
   float na[2], nb[2], nd[2];
   fetch(0, na, nb, nd);
@@ -454,6 +475,13 @@ ssim_bwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
         }
         ss_wave_sync();
         if (j + 1 < rows_in) fetch(j + 1, na, nb, nd);
+        const float x = x_next, y = y_next;                  // pixel of output row j - 10
+        if (j + 1 >= 2 * SSIM_R && j + 1 < rows_in && gx < W) {   // output row j + 1 - 10 exists
+          x_next = *px;
+          y_next = *py;
+          px += v1.sh;
+          py += v2.sh;
+        }
         float t[11];
 #pragma unroll
         for (int k = 0; k < 11; ++k) t[k] = buf[0][lane + k];
@@ -465,7 +493,6 @@ ssim_bwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
         for (int k = 0; k < 11; ++k) t[k] = buf[2][lane + k];
         wd[sl] = sym11(t);
         if (j >= 2 * SSIM_R) {
-          const int gy = y0 + j - 2 * SSIM_R;
           float oa[11], ob[11], od[11];
 #pragma unroll
           for (int k = 0; k < 11; ++k) {
@@ -476,11 +503,10 @@ ssim_bwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
           }
           const float a = sym11(oa), b = sym11(ob), d = sym11(od);
           if (gx < W) {
-            const float x = img1[n * v1.sn + c * v1.sc + gy * v1.sh + gx * v1.sw];
-            const float y = img2[n * v2.sn + c * v2.sc + gy * v2.sh + gx * v2.sw];
             const float df = x - y;
             const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-            grad[n * vg.sn + c * vg.sc + gy * vg.sh + gx * vg.sw] = w_l1 * sgn + w_ssim * (a + 2.f * x * b + y * d);
+            *pg = w_l1 * sgn + w_ssim * (a + 2.f * x * b + y * d);
+            pg += vg.sh;
           }
         }
       }
