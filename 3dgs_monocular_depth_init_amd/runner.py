@@ -353,6 +353,7 @@ def train(
     seed: int = 42,
     progress=None,                  # callable(step, stats_dict) every `progress_every` steps (stands in for tqdm / tensorboard)
     progress_every: int = 100,
+    device_cache_bytes: int = 64 << 30,   # frames kept resident on the device once used (0: none), see below
 ) -> Dict:
     """Runner.train (runner.py:367-709) around `train_step`, with the reference's schedule:
 
@@ -419,13 +420,35 @@ def train(
     B, W = int(cfg.batch_size), int(world_size)
     order: list = []
 
+    # Frames stay on the device once they have been used, as the batch entries the step consumes: the image as
+    # [1,H,W,3] float32 in [0,1] (the reference uploads and divides by 255 on every step, runner.py:446: 25 MB over
+    # PCIe per 1080p frame -- longer than a step takes here -- and, for frames already on the device, one element-wise
+    # launch per step), poses / intrinsics / masks / depth points as [1, ...]. 100 views at 1080p are 2.5 GB of the
+    # 288; beyond `device_cache_bytes` frames are prepared per step as before.
+    resident: dict = {}
+    resident_bytes = 0
+
+    def prepared(i):
+        nonlocal resident_bytes
+        hit = resident.get(i)
+        if hit is not None:
+            return hit
+        d = trainset[i]
+        e = {k: d[k].to(device)[None] for k in ("camtoworld", "K", "mask", "points", "depths") if k in d}
+        e["pixels"] = d["image"].to(device)[None].float() / 255.0
+        size = sum(t.numel() * t.element_size() for t in e.values())
+        if resident_bytes + size <= device_cache_bytes:
+            resident[i] = e
+            resident_bytes += size
+        return e
+
     def next_batch():
         nonlocal order
         need = B * W
         if len(order) < need:                       # DataLoader(shuffle=True): a fresh permutation per epoch
             order = order + torch.randperm(n_train, generator=gen).tolist()
         take, order = order[:need], order[need:]
-        return [trainset[i] for i in take[world_rank::W]], take
+        return [prepared(i) for i in take[world_rank::W]], take
 
     save_at = {i - 1 for i in cfg.save_steps} | {max_steps - 1}
     eval_at = {i - 1 for i in cfg.eval_steps}
@@ -445,11 +468,11 @@ def train(
                     raise ValueError("the row exchange renders one view per rank per step (cfg.batch_size = 1)")
                 grad_sync.set_views(torch.stack([trainset[i]["camtoworld"].to(device) for i in everyone]),
                                     torch.stack([trainset[i]["K"].to(device) for i in everyone]))
-            def batch_of(key):       # the DataLoader's collation; one frame (cfg.batch_size 1) is a view, not a copy launch
-                return data[0][key].to(device)[None] if len(data) == 1 else torch.stack([d[key].to(device) for d in data])
+            def batch_of(key):       # the DataLoader's collation; one frame (cfg.batch_size 1) is used as it is
+                return data[0][key] if len(data) == 1 else torch.cat([d[key] for d in data])
 
             c2w, Ks = batch_of("camtoworld"), batch_of("K")
-            pixels = batch_of("image").float() / 255.0
+            pixels = batch_of("pixels")
             masks = batch_of("mask") if "mask" in data[0] else None
             extra = {}
             if cfg.depth_loss:                                                         # runner.py:450-452
