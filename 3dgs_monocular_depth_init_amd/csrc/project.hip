@@ -552,18 +552,27 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
                          const float *__restrict__ v_comps, int depth_channel,
                          const float *__restrict__ opacities_act, AdamFused af) {
   __shared__ __attribute__((aligned(16))) float sT[GSR_PBWD1_WAVES * 64 * 45];   // per-wave slabs: shN rows, then their gradients
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;                    // N is a multiple of 64: whole waves leave
   const int lane = threadIdx.x & 63;
+  const int wave_first = blockIdx.x * blockDim.x + threadIdx.x - lane;
+  if (wave_first >= N) return;           // whole waves leave
+  // The last wave may hold fewer than 64 Gaussians (N is whatever densification left): its idle lanes redo the last
+  // Gaussian's arithmetic (in-bounds reads) and store nothing; the cooperative phases -- the slab DMA and the Adam pass
+  // over the wave's contiguous block of shN -- stop at the last valid float. (That tail used to go to the generic
+  // kernel in a launch of its own: 31 us, serial, on every step of a real run -- profiles/r04_c5_full_kernel_stats.csv.)
+  const int n_valid = min(64, N - wave_first);
+  const bool active = lane < n_valid;
+  const int i = active ? wave_first + lane : N - 1;
+  const int n_full = (n_valid * 45) >> 2, n_rem = (n_valid * 45) & 3;     // whole 16-byte pieces of the block, floats left over
   float *slab = &sT[(threadIdx.x >> 6) * (64 * 45)];
   float *const P_shN = af.p[AF_SHN];
   {
-    const float *src = P_shN + (int64_t)(i - lane) * 45;
+    const float *src = P_shN + (int64_t)wave_first * 45;
 #pragma unroll
     for (int it = 0; it < 12; ++it) {
       const int idx = it * 64 + lane;
-      if (idx < 64 * 45 / 4) dma_16B(src + 4 * idx, slab + 256 * it);
+      if (idx < n_full) dma_16B(src + 4 * idx, slab + 256 * it);
     }
+    if (lane < n_rem) slab[4 * n_full + lane] = src[4 * n_full + lane];
   }
   // the short rows: parameters (kept for their own Adam update below), gradient row, visibility
   const float *pm = af.p[AF_MEANS] + (int64_t)i * 3, *pq = af.p[AF_QUATS] + (int64_t)i * 4,
@@ -640,7 +649,7 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
 #pragma unroll
   for (int it = 0; it < 12; ++it) {
     const int idx = it * 64 + lane;
-    p_lin[it] = (idx < 64 * 45 / 4) ? reinterpret_cast<const float4 *>(slab)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    p_lin[it] = (idx < n_full) ? reinterpret_cast<const float4 *>(slab)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #endif
   if (visible) {
@@ -711,9 +720,11 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
     auto upd = [&](int t, int64_t off, float pp, float g, int j) {
       float mm = m_s[j], vv = v_m[j];
       adam_one(pp, g, mm, vv, af.omb1, af.beta2, af.omb2, af.eps, af.step_size[t], af.bc2_sqrt[t]);
-      af.p[t][off] = pp;
-      af.m[t][off] = mm;
-      af.v[t][off] = vv;
+      if (active) {
+        af.p[t][off] = pp;
+        af.m[t][off] = mm;
+        af.v[t][off] = vv;
+      }
     };
     const int64_t o3 = (int64_t)i * 3, o4 = (int64_t)i * 4;
 #pragma unroll
@@ -729,7 +740,7 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
   // Adam on the wave's contiguous 64 x 45 block of shN / exp_avg / exp_avg_sq, coalesced 16-byte pieces,
   // gradients from the slab (written row-wise above, read linearly here)
   {
-    const int64_t base = (int64_t)(i - lane) * 45;
+    const int64_t base = (int64_t)wave_first * 45;
     float4 *P4 = reinterpret_cast<float4 *>(P_shN + base);
     float4 *M4 = reinterpret_cast<float4 *>(af.m[AF_SHN] + base);
     float4 *V4 = reinterpret_cast<float4 *>(af.v[AF_SHN] + base);
@@ -743,7 +754,7 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
 #endif
     for (int it = 0; it < 12; ++it) {
       const int idx = it * 64 + lane;
-      if (idx < 64 * 45 / 4) {
+      if (idx < n_full) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const f4v mmv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&M4[idx]));
         const f4v vvv = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(&V4[idx]));
@@ -763,6 +774,14 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
         __builtin_nontemporal_store(mo, reinterpret_cast<f4v *>(&M4[idx]));
         __builtin_nontemporal_store(vo, reinterpret_cast<f4v *>(&V4[idx]));
       }
+    }
+    if (lane < n_rem) {      // (last wave only) the one to three floats behind the last whole piece
+      const int64_t e = base + 4 * n_full + lane;
+      float pp = P_shN[e], mm = af.m[AF_SHN][e], vv = af.v[AF_SHN][e];
+      adam_one(pp, slab[4 * n_full + lane], mm, vv, af.omb1, af.beta2, af.omb2, af.eps, ss, bc2);
+      P_shN[e] = pp;
+      af.m[AF_SHN][e] = mm;
+      af.v[AF_SHN][e] = vv;
     }
   }
 }
@@ -1026,14 +1045,14 @@ static int project_bwd_adam_impl(int C, int N, const float *viewmats, const floa
   af.opacity_reg = opacity_reg / (float)N;
   af.scale_reg = scale_reg / (3.0f * (float)N);
   const bool extras = noise != nullptr || opacity_reg != 0.f || scale_reg != 0.f;
-  // One camera, fp32 scratch rows, 16-byte aligned shN blocks: the whole waves go to the single-camera
-  // kernel, a last partial wave (N % 64 Gaussians) to the generic one.
+  // One camera, fp32 scratch rows, 16-byte aligned shN blocks: the single-camera kernel; everything else (several
+  // cameras, packed rows, unaligned blocks) the generic one.
   int n_fast = 0;
 #ifndef GSR_PBWD_GENERIC_ONLY
   if (C == 1 && grad_stride == GSR_GRAD_ROW && radii &&
       ((((uintptr_t)af.p[gsr::AF_SHN]) | ((uintptr_t)af.m[gsr::AF_SHN]) | ((uintptr_t)af.v[gsr::AF_SHN]) |
         ((uintptr_t)grad_rows)) & 15) == 0 && (((uintptr_t)radii) & 7) == 0)
-    n_fast = N & ~63;
+    n_fast = N;            // (a last partial wave included)
 #endif
   if (n_fast > 0) {
     const dim3 grid((unsigned)gsr::ceil_div(n_fast, 64 * GSR_PBWD1_WAVES)), block(64 * GSR_PBWD1_WAVES);

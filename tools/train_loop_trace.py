@@ -32,7 +32,7 @@ from tests import scenes  # noqa: E402
 P = "3dgs_monocular_depth_init_amd."
 runner = importlib.import_module(P + "runner")
 cfgm = importlib.import_module(P + "config")
-N, W, H = 200_000, 1920, 1080
+N, W, H = (200_037 if "--odd" in sys.argv else 200_000), 1920, 1080
 sc = scenes.make_scene(N, 3)
 vms, Ks = scenes.cameras(range(0, 100, 10), width=W, height=H, f=1200.0)
 c2ws = torch.linalg.inv(vms).contiguous().cuda()
