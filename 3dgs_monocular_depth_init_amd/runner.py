@@ -434,8 +434,10 @@ def train(
         if hit is not None:
             return hit
         d = trainset[i]
-        e = {k: d[k].to(device)[None] for k in ("camtoworld", "K", "mask", "points", "depths") if k in d}
-        e["pixels"] = d["image"].to(device)[None].float() / 255.0
+        # (contiguous once, here: a camtoworld that came out of torch.linalg.inv is column-major, and the 4x4 inverse
+        # launch would re-pack it on every step)
+        e = {k: d[k].to(device)[None].contiguous() for k in ("camtoworld", "K", "mask", "points", "depths") if k in d}
+        e["pixels"] = (d["image"].to(device)[None].float() / 255.0).contiguous()
         size = sum(t.numel() * t.element_size() for t in e.values())
         if resident_bytes + size <= device_cache_bytes:
             resident[i] = e
