@@ -51,7 +51,16 @@ SIGNATURES["gsr_pack_grad_rows"] = [_i64, _p, _p, _p, _p]
 SIGNATURES["gsr_pack_grad_rows_h"] = [_i64, _p, _p, _p, _p]
 SIGNATURES["gsr_project_bwd_adam"] = [_i, _i, _p, _p, _p, _i, _i, _f, _i, _p, _p, _i, _p, _p, _i, _i, _p,
                                       _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_double, _p]
-SIGNATURES["gsr_project_bwd_adam_mcmc"] = SIGNATURES["gsr_project_bwd_adam"][:-1] + [_p, C.c_double, C.c_double, C.c_double, _p]
+
+
+class StepExtras(C.Structure):      # gsr_step_extras (include/gsrast.h)
+    _fields_ = [("noise", C.c_void_p), ("noise_scale", C.c_double), ("opacity_reg", C.c_double), ("scale_reg", C.c_double),
+                ("stat_grad2d", C.c_void_p), ("stat_count", C.c_void_p), ("stat_radii", C.c_void_p),
+                ("stat_sx", C.c_double), ("stat_sy", C.c_double), ("stat_inv_max_wh", C.c_double),
+                ("stat_use_absgrad", C.c_int)]
+
+
+SIGNATURES["gsr_project_bwd_adam_ex"] = SIGNATURES["gsr_project_bwd_adam"][:-1] + [C.POINTER(StepExtras), _p]
 SIGNATURES["gsr_project_bwd_rows"] = [_i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _i, _p,
                                       _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p]
 SIGNATURES["gsr_strategy_accumulate"] = [_i, _i, _p, _i, _p, _f, _f, _p, _p, _p, _f, _p]

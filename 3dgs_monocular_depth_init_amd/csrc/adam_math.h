@@ -32,6 +32,12 @@ struct AdamFused {
   float noise_scale;           // lr(means) * noise_lr
   float opacity_reg;           // opacity_reg / N        (x sigmoid' = s (1 - s) in the kernel)
   float scale_reg;             // scale_reg / (3 N)      (x exp(s) in the kernel)
+  // DefaultStrategy's per-step statistics (gsplat DefaultStrategy._update_state, runner.py:639-647), taken while the
+  // gradient row and the radii are in registers anyway: grad2d[i] += |(g.x sx, g.y sy)|, count[i] += 1 per camera that
+  // renders Gaussian i, radii[i] = max(radii[i], max(rx, ry) / max(W, H)). NULL: not wanted.
+  float *stat_grad2d, *stat_count, *stat_radii;
+  float stat_sx, stat_sy, stat_inv_max_wh;
+  int stat_abs;                // 1: from the absgrad fields of the row (GSR_GR_ABS) instead of GSR_GR_MEAN2D
 };
 
 // gate(1 - opacity) * scaler of gsplat's inject_noise_to_position (op_sigmoid with k = 100, x0 = 0.995)

@@ -288,6 +288,7 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     cn_row = slab + lane * 45;
   }
 
+  float stat_acc = 0.f, stat_cnt = 0.f, stat_rmax = 0.f;
   for (int c = 0; c < C; ++c) {
     int64_t g = (int64_t)c * N + i;
     const float *row = grad_rows + g * row_stride;
@@ -319,6 +320,15 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
 #pragma unroll
       for (int k = 0; k < GSR_PACKED_ROW; ++k) any |= (rv[k] != 0.f);
       if (!any) continue;
+    }
+    if constexpr (FUSE_ADAM) {
+      if (af.stat_grad2d && radii && row_stride == GSR_GRAD_ROW) {     // DefaultStrategy statistics (AdamFused, adam_math.h)
+        const float gx = (af.stat_abs ? row[GSR_GR_ABS] : rv[GSR_GR_MEAN2D]) * af.stat_sx;
+        const float gy = (af.stat_abs ? row[GSR_GR_ABS + 1] : rv[GSR_GR_MEAN2D + 1]) * af.stat_sy;
+        stat_acc += sqrtf(gx * gx + gy * gy);
+        stat_cnt += 1.f;
+        stat_rmax = fmaxf(stat_rmax, (float)max(radii[g * 2], radii[g * 2 + 1]) * af.stat_inv_max_wh);
+      }
     }
     v_op += rv[GSR_GR_OPAC];
     float v_m2d[2] = {rv[GSR_GR_MEAN2D], rv[GSR_GR_MEAN2D + 1]};
@@ -381,6 +391,11 @@ project_bwd_kernel(int C, int N, const float *__restrict__ means, const float *_
     v_op *= o * (1.0f - o);
   }
   if constexpr (FUSE_ADAM) {
+    if (af.stat_grad2d && stat_cnt > 0.f) {
+      af.stat_grad2d[i] += stat_acc;
+      af.stat_count[i] += stat_cnt;
+      if (af.stat_radii) af.stat_radii[i] = fmaxf(af.stat_radii[i], stat_rmax);
+    }
     // the mcmc preset's extras (AdamFused, adam_math.h): zero / NULL otherwise
     float noise_add[3] = {0.f, 0.f, 0.f};
     if (af.opacity_reg != 0.f || af.scale_reg != 0.f || af.noise) {
@@ -703,6 +718,18 @@ project_bwd_adam1_kernel(int N, const float *__restrict__ viewmat, const float *
       }
   }
   if constexpr (EXTRAS) {
+    if (af.stat_grad2d && visible && active) {
+      float gx = r0.x, gy = r0.y;
+      if (af.stat_abs) {
+        gx = grad_rows[(int64_t)i * GSR_GRAD_ROW + GSR_GR_ABS];
+        gy = grad_rows[(int64_t)i * GSR_GRAD_ROW + GSR_GR_ABS + 1];
+      }
+      gx *= af.stat_sx;
+      gy *= af.stat_sy;
+      af.stat_grad2d[i] += sqrtf(gx * gx + gy * gy);
+      af.stat_count[i] += 1.f;
+      if (af.stat_radii) af.stat_radii[i] = fmaxf(af.stat_radii[i], (float)max(rad.x, rad.y) * af.stat_inv_max_wh);
+    }
     v_op += af.opacity_reg * o_act * (1.0f - o_act);
 #pragma unroll
     for (int k = 0; k < 3; ++k) v_s[k] += af.scale_reg * s[k];
@@ -1012,8 +1039,7 @@ static int project_bwd_adam_impl(int C, int N, const float *viewmats, const floa
                                  void *const *params, void *const *exp_avg,
                                  void *const *exp_avg_sq, const float *step_size,
                                  const float *bc2_sqrt, double beta1_d, double beta2_d,
-                                 double eps_d, const float *noise, float noise_scale, float opacity_reg,
-                                 float scale_reg, void *stream) {
+                                 double eps_d, const gsr_step_extras *ex, void *stream) {
   GSR_REQUIRE(C >= 0 && N >= 0, "project_bwd_adam: bad sizes");
   if (N == 0) return GSR_OK;
   GSR_REQUIRE(viewmats && Ks && campos && grad_rows && params && exp_avg && exp_avg_sq &&
@@ -1040,11 +1066,20 @@ static int project_bwd_adam_impl(int C, int N, const float *viewmats, const floa
   af.eps = (float)eps_d;
   af.omb1 = (float)(1.0 - beta1_d);
   af.omb2 = (float)(1.0 - beta2_d);
-  af.noise = noise;
-  af.noise_scale = noise_scale;
-  af.opacity_reg = opacity_reg / (float)N;
-  af.scale_reg = scale_reg / (3.0f * (float)N);
-  const bool extras = noise != nullptr || opacity_reg != 0.f || scale_reg != 0.f;
+  af.noise = ex ? ex->noise : nullptr;
+  af.noise_scale = ex ? (float)ex->noise_scale : 0.f;
+  af.opacity_reg = ex ? (float)(ex->opacity_reg / (double)N) : 0.f;
+  af.scale_reg = ex ? (float)(ex->scale_reg / (3.0 * (double)N)) : 0.f;
+  af.stat_grad2d = ex ? ex->stat_grad2d : nullptr;
+  af.stat_count = ex ? ex->stat_count : nullptr;
+  af.stat_radii = ex ? ex->stat_radii : nullptr;
+  af.stat_sx = ex ? (float)ex->stat_sx : 0.f;
+  af.stat_sy = ex ? (float)ex->stat_sy : 0.f;
+  af.stat_inv_max_wh = ex ? (float)ex->stat_inv_max_wh : 0.f;
+  af.stat_abs = ex ? ex->stat_use_absgrad : 0;
+  GSR_REQUIRE(!af.stat_grad2d || (af.stat_count && grad_stride == GSR_GRAD_ROW && radii),
+              "project_bwd_adam: the strategy statistics need the fp32 scratch rows, the radii and a count array");
+  const bool extras = af.noise != nullptr || af.opacity_reg != 0.f || af.scale_reg != 0.f || af.stat_grad2d != nullptr;
   // One camera, fp32 scratch rows, 16-byte aligned shN blocks: the single-camera kernel; everything else (several
   // cameras, packed rows, unaligned blocks) the generic one.
   int n_fast = 0;
@@ -1077,6 +1112,11 @@ static int project_bwd_adam_impl(int C, int N, const float *viewmats, const floa
       at.v[t] += a0 * row_floats[t];
     }
     if (at.noise) at.noise += a0 * 3;
+    if (at.stat_grad2d) {
+      at.stat_grad2d += a0;
+      at.stat_count += a0;
+      if (at.stat_radii) at.stat_radii += a0;
+    }
     // (with n_fast > 0 this is C == 1: per-Gaussian arrays simply start a0 rows later)
     hipLaunchKernelGGL(gsr::project_bwd_kernel<true>, dim3((unsigned)gsr::ceil_div(n_rest, 256)), dim3(256), 0,
                        (hipStream_t)stream, C, n_rest, at.p[gsr::AF_MEANS], at.p[gsr::AF_QUATS],
@@ -1103,25 +1143,23 @@ extern "C" int gsr_project_bwd_adam(int C, int N, const float *viewmats, const f
   return project_bwd_adam_impl(C, N, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii, grad_rows,
                                grad_stride, v_depths, v_compensations, depth_channel, activations, opacities_act,
                                params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1_d, beta2_d, eps_d, nullptr,
-                               0.f, 0.f, 0.f, stream);
+                               stream);
 }
 
-// The same pass with what the "mcmc" preset adds to a step (see AdamFused in adam_math.h): position noise from
-// `noise` [N,3] (NULL: none) scaled by noise_scale = lr(means) * noise_lr, and the gradients of
-// opacity_reg * mean(sigmoid(opacities)) + scale_reg * mean(exp(scales)).
-extern "C" int gsr_project_bwd_adam_mcmc(int C, int N, const float *viewmats, const float *Ks,
-                                         const float *campos, int width, int height, float eps2d,
-                                         int sh_degree, const int32_t *radii, const float *grad_rows,
-                                         int grad_stride, const float *v_depths,
-                                         const float *v_compensations,
-                                         int depth_channel, int activations, const float *opacities_act,
-                                         void *const *params, void *const *exp_avg,
-                                         void *const *exp_avg_sq, const float *step_size,
-                                         const float *bc2_sqrt, double beta1_d, double beta2_d,
-                                         double eps_d, const float *noise, double noise_scale,
-                                         double opacity_reg, double scale_reg, void *stream) {
+// The same pass with what else a training step does to every Gaussian riding along (gsr_step_extras, gsrast.h): the
+// "mcmc" preset's position noise and regulariser gradients, DefaultStrategy's per-step statistics.
+extern "C" int gsr_project_bwd_adam_ex(int C, int N, const float *viewmats, const float *Ks,
+                                       const float *campos, int width, int height, float eps2d,
+                                       int sh_degree, const int32_t *radii, const float *grad_rows,
+                                       int grad_stride, const float *v_depths,
+                                       const float *v_compensations,
+                                       int depth_channel, int activations, const float *opacities_act,
+                                       void *const *params, void *const *exp_avg,
+                                       void *const *exp_avg_sq, const float *step_size,
+                                       const float *bc2_sqrt, double beta1_d, double beta2_d,
+                                       double eps_d, const gsr_step_extras *extras, void *stream) {
   return project_bwd_adam_impl(C, N, viewmats, Ks, campos, width, height, eps2d, sh_degree, radii, grad_rows,
                                grad_stride, v_depths, v_compensations, depth_channel, activations, opacities_act,
-                               params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1_d, beta2_d, eps_d, noise,
-                               (float)noise_scale, (float)opacity_reg, (float)scale_reg, stream);
+                               params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1_d, beta2_d, eps_d, extras,
+                               stream);
 }

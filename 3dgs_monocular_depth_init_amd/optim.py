@@ -150,12 +150,16 @@ class FusedAdam:
 
     # ---- optimizer in backward ------------------------------------------------------
     FUSED_ORDER = ("means", "quats", "scales", "opacities", "sh0", "shN")
-    # What the "mcmc" preset adds to ONE step, applied inside the fused backward (gsr_project_bwd_adam_mcmc): set by
-    # runner.train_step before loss.backward(), consumed (and cleared) by the projection backward.
-    step_extras = None      # (noise [N,3] or None, noise_scale, opacity_reg, scale_reg)
+    # What else ONE step does to every Gaussian, applied inside the fused backward (gsr_project_bwd_adam_ex,
+    # gsr_step_extras): the "mcmc" preset's position noise and regulariser gradients, DefaultStrategy's statistics.
+    # Set by runner.train_step before loss.backward(), consumed (and cleared) by the projection backward.
+    step_extras = None      # dict: noise, noise_scale, opacity_reg, scale_reg, stats
 
-    def set_step_extras(self, noise, noise_scale: float, opacity_reg: float, scale_reg: float) -> None:
-        self.step_extras = (noise, float(noise_scale), float(opacity_reg), float(scale_reg))
+    def set_step_extras(self, noise=None, noise_scale: float = 0.0, opacity_reg: float = 0.0, scale_reg: float = 0.0,
+                        stats=None) -> None:
+        """stats: (grad2d [N], count [N], radii_state [N] or None, sx, sy, inv_max_wh, use_absgrad)."""
+        self.step_extras = dict(noise=noise, noise_scale=float(noise_scale), opacity_reg=float(opacity_reg),
+                                scale_reg=float(scale_reg), stats=stats)
 
     def take_step_extras(self):
         ex, self.step_extras = self.step_extras, None

@@ -266,12 +266,17 @@ class _ProjectSH(torch.autograd.Function):
                              off(V), ss, bc2, beta1, beta2, eps, _stream())
                     return (None,) * 10
                 extras = bo.take_step_extras() if hasattr(bo, "take_step_extras") else None
-                if extras is not None:       # the "mcmc" preset: position noise + regulariser gradients in the same pass
-                    noise, noise_scale, opacity_reg, scale_reg = extras
-                    call("gsr_project_bwd_adam_mcmc", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
+                if extras is not None:       # mcmc noise / regulariser gradients / strategy statistics in the same pass
+                    import ctypes
+                    st = extras.get("stats")
+                    ex = _lib.StepExtras(ptr(extras.get("noise")), extras["noise_scale"], extras["opacity_reg"],
+                                         extras["scale_reg"], ptr(st[0]) if st else None, ptr(st[1]) if st else None,
+                                         ptr(st[2]) if st else None, st[3] if st else 0.0, st[4] if st else 0.0,
+                                         st[5] if st else 0.0, int(bool(st[6])) if st else 0)
+                    call("gsr_project_bwd_adam_ex", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
                          height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),
                          ptr(v_comps), depth_channel, activations, ptr(opac_act), P, M, V, ss, bc2,
-                         beta1, beta2, eps, ptr(noise), noise_scale, opacity_reg, scale_reg, _stream())
+                         beta1, beta2, eps, ctypes.byref(ex), _stream())
                 else:
                     call("gsr_project_bwd_adam", C, N, ptr(viewmats), ptr(Ks), ptr(campos), width,
                          height, eps2d, sh_degree, ptr(radii), ptr(rows), GRAD_ROW, ptr(v_depths),

@@ -202,7 +202,7 @@ def train_step(
     fused = _R._BACKWARD_OPTIMIZER
     regs = opacity_reg > 0.0 or scale_reg > 0.0
     # The fused backward can take the "mcmc" preset's extras along (optim.FusedAdam.set_step_extras ->
-    # gsr_project_bwd_adam_mcmc): the regularisers' gradients, and MCMCStrategy's position noise on the steps between
+    # gsr_project_bwd_adam_ex): the regularisers' gradients, and MCMCStrategy's position noise on the steps between
     # refinements -- computed from the pre-update parameters and added before the Adam update, i.e. the reference's
     # strategy-then-optimizer order (runner.py:649-679). Single rank only.
     extras_ok = fused is not None and hasattr(fused, "set_step_extras") and grad_sync is None
@@ -212,7 +212,13 @@ def train_step(
     # optimizer (runner.py:638-679); the fused update would land before the strategy
     ordered = fused is not None and ((strategy is not None and strategy.mutates_params(step) and not mcmc_noise)
                                      or before_update is not None)
-    use_extras = extras_ok and not ordered and (regs or mcmc_noise)
+    # DefaultStrategy's per-step statistics travel the same way (the rows and radii are in the kernel's registers)
+    from .strategy import DefaultStrategy
+    stats = None
+    if (extras_ok and not ordered and isinstance(strategy, DefaultStrategy) and step < strategy.refine_stop_iter
+            and camtoworlds.shape[0] == 1 and not cfg.packed):
+        stats = strategy.stats_for_fused_backward(splats, strategy_state, info)
+    use_extras = extras_ok and not ordered and (regs or mcmc_noise or stats is not None)
     reg_value = None
     if regs and use_extras:             # their gradients come from the fused backward; the VALUE still belongs to the loss
         with torch.no_grad():
@@ -240,7 +246,7 @@ def train_step(
         if mcmc_noise:
             noise = strategy.draw_noise(splats, strategy_state)
             noise_scale = optimizers["means"].param_groups[0]["lr"] * strategy.noise_lr
-        fused.set_step_extras(noise, noise_scale, opacity_reg, scale_reg)
+        fused.set_step_extras(noise, noise_scale, opacity_reg, scale_reg, stats)
     try:
         one = unit_gradient(loss.device)
         loss.backward(one if one.dtype == loss.dtype else None)          # runner.py:547 (root
@@ -263,7 +269,8 @@ def train_step(
             strategy.step_post_backward(splats, optimizers, strategy_state, step, info, lr=means_lr,
                                         noise_done=mcmc_noise)
         else:
-            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed)
+            strategy.step_post_backward(splats, optimizers, strategy_state, step, info, packed=cfg.packed,
+                                        **({"stats_done": True} if stats is not None else {}))
     if optimizers is not None:
         from .optim import FusedSparseAdam
         if isinstance(optimizers, FusedSparseAdam):                      # cfg.sparse_grad, one launch

@@ -248,11 +248,29 @@ class DefaultStrategy:
                   and step % self.reset_every >= self.pause_refine_after_reset)
         return refine or (step % self.reset_every == 0 and step > 0)
 
+    def stats_for_fused_backward(self, params, state, info):
+        """The launch arguments of this step's statistics for a backward that takes them along
+        (optim.FusedAdam.set_step_extras(stats=...)): (grad2d, count, radii_state or None, sx, sy, 1 / max(W, H),
+        absgrad), the accumulators allocated as `_update_state` would. None when they do not apply."""
+        if self.key_for_gradient != "means2d" or not params["means"].is_cuda:
+            return None
+        n = len(params["means"])
+        dev = params["means"].device
+        if state["grad2d"] is None:
+            state["grad2d"] = torch.zeros(n, device=dev)
+            state["count"] = torch.zeros(n, device=dev)
+        if self.refine_scale2d_stop_iter > 0 and state["radii"] is None:
+            state["radii"] = torch.zeros(n, device=dev)
+        return (state["grad2d"], state["count"], state["radii"] if self.refine_scale2d_stop_iter > 0 else None,
+                info["width"] / 2.0 * info["n_cameras"], info["height"] / 2.0 * info["n_cameras"],
+                1.0 / float(max(info["width"], info["height"])), bool(self.absgrad))
+
     def step_post_backward(self, params, optimizers, state, step: int, info: Dict[str, Any],
-                           packed: bool = False) -> None:
+                           packed: bool = False, stats_done: bool = False) -> None:
         if step >= self.refine_stop_iter:
             return
-        self._update_state(params, state, info, packed=packed)
+        if not stats_done:          # (True: the fused backward accumulated them, runner.train_step)
+            self._update_state(params, state, info, packed=packed)
         if (step > self.refine_start_iter and step % self.refine_every == 0
                 and step % self.reset_every >= self.pause_refine_after_reset):
             self._sync_state(state)

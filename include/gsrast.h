@@ -154,20 +154,31 @@ int gsr_project_bwd_adam(int C, int N, const float *viewmats, const float *Ks, c
                          const float *opacities_act, void *const *params, void *const *exp_avg,
                          void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
                          double beta1, double beta2, double eps, void *stream);
-/* The same pass with what the reference's "mcmc" preset adds to every step (trainer.py:83-92): the position
- * noise of gsplat's MCMCStrategy.step_post_backward -> inject_noise_to_position (runner.py:649-656; means +=
- * covar . (noise * gate(1 - opacity) * noise_scale), from the PRE-update parameters, applied before the Adam
- * update of the means as in the reference's strategy-then-optimizer order) and the gradients of the two
- * regularisers opacity_reg * mean(sigmoid(opacities)) + scale_reg * mean(exp(scales)) (runner.py:535-545).
- * noise: [N,3] standard-normal draws or NULL; noise_scale = lr(means) * noise_lr. */
-int gsr_project_bwd_adam_mcmc(int C, int N, const float *viewmats, const float *Ks, const float *campos,
-                              int width, int height, float eps2d, int sh_degree, const int32_t *radii,
-                              const float *grad_rows, int grad_stride, const float *v_depths,
-                              const float *v_compensations, int depth_channel, int activations,
-                              const float *opacities_act, void *const *params, void *const *exp_avg,
-                              void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
-                              double beta1, double beta2, double eps, const float *noise, double noise_scale,
-                              double opacity_reg, double scale_reg, void *stream);
+/* What else a training step does to every Gaussian, riding along in the same pass (all optional):
+ *  - the reference's "mcmc" preset (trainer.py:83-92): the position noise of gsplat's
+ *    MCMCStrategy.step_post_backward -> inject_noise_to_position (runner.py:649-656; means += covar . (noise *
+ *    gate(1 - opacity) * noise_scale), from the PRE-update parameters, applied before the Adam update of the means as
+ *    in the reference's strategy-then-optimizer order) and the gradients of the two regularisers
+ *    opacity_reg * mean(sigmoid(opacities)) + scale_reg * mean(exp(scales)) (runner.py:535-545);
+ *  - gsplat's DefaultStrategy._update_state (runner.py:639-647): grad2d[i] += |(g.x sx, g.y sy)| (g = the 2-D mean
+ *    gradient of the row, or its absgrad fields), count[i] += 1 per camera rendering i, radii[i] = max(radii[i],
+ *    max(rx, ry) * inv_max_wh); needs the fp32 scratch rows and the radii. */
+typedef struct gsr_step_extras {
+  const float *noise;        /* NULL or [N,3] standard-normal draws */
+  double noise_scale;        /* lr(means) * noise_lr */
+  double opacity_reg, scale_reg;
+  float *stat_grad2d, *stat_count /* [N], NULL: no statistics */, *stat_radii /* [N] or NULL */;
+  double stat_sx, stat_sy, stat_inv_max_wh;
+  int stat_use_absgrad;
+} gsr_step_extras;
+int gsr_project_bwd_adam_ex(int C, int N, const float *viewmats, const float *Ks, const float *campos,
+                            int width, int height, float eps2d, int sh_degree, const int32_t *radii,
+                            const float *grad_rows, int grad_stride, const float *v_depths,
+                            const float *v_compensations, int depth_channel, int activations,
+                            const float *opacities_act, void *const *params, void *const *exp_avg,
+                            void *const *exp_avg_sq, const float *step_size, const float *bc2_sqrt,
+                            double beta1, double beta2, double eps, const gsr_step_extras *extras /* or NULL */,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------
  * A5: per-tile depth-sorted intersection lists.

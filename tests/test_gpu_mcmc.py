@@ -155,7 +155,7 @@ def test_gather_launch_paths_equal_the_tensor_ops(op, monkeypatch):
 
 @pytest.mark.parametrize("N", [2000, 2043])      # whole waves only / a 59-Gaussian tail through the generic kernel
 def test_mcmc_step_fused_into_backward_equals_reference_order(N):
-    """The "mcmc" preset's step with the optimizer in the backward (gsr_project_bwd_adam_mcmc: Adam + the position
+    """The "mcmc" preset's step with the optimizer in the backward (gsr_project_bwd_adam_ex: Adam + the position
     noise from the pre-update parameters + the gradients of the opacity / scale regularisers in ONE pass) against the
     reference's order -- backward, regularisers through autograd, strategy.step_post_backward (noise), optimizer.step
     (runner.py:535-547, 649-679) -- on two copies of a scene, same noise generator seed, across refine steps (which
@@ -207,7 +207,7 @@ def test_mcmc_step_fused_into_backward_equals_reference_order(N):
         out[fuse] = (losses, {k: v.detach().clone() for k, v in splats.items()},
                      {k: fused[k].state[splats[k]]["exp_avg_sq"].clone() for k in splats})
         if fuse:
-            assert calls.count("gsr_project_bwd_adam_mcmc") == 10        # every step but the two refine steps (5, 10)
+            assert calls.count("gsr_project_bwd_adam_ex") == 10        # every step but the two refine steps (5, 10)
             calls.clear()
     (l1, p1, v1), (l0, p0, v0) = out[True], out[False]
     assert max(abs(a - b) for a, b in zip(l1, l0)) < 1e-6

@@ -378,7 +378,7 @@ def test_fused_backward_with_strategy_keeps_reference_order():
 def test_fused_backward_refuses_gradients_from_outside_the_rasterizer():
     """the MCMC preset's opacity / scale regularisers reach the parameters
     outside the rasterizer; with optimizer-in-backward they used to be applied in a SECOND Adam
-    step. Since round 4 `train_step` hands them to the fused backward (gsr_project_bwd_adam_mcmc; same
+    step. Since round 4 `train_step` hands them to the fused backward (gsr_project_bwd_adam_ex; same
     parameters as the autograd route, checked here), and FusedAdam.step() still raises on any stray gradient."""
     from tests import scenes
     runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
@@ -666,3 +666,65 @@ def test_sparse_grad_one_launch_equals_reference_sparse_adam(batch):
             assert float(y[~seen].abs().max()) == 0.0, (n, a)              # never rendered: moments stay zero
         assert torch.equal(p_fus[n][~seen], s0[n][~seen]), n                # ... and the parameter untouched
     assert float((p_fus["means"][seen] - s0["means"][seen]).abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("absgrad,scale2d_stop", [(False, 0), (True, 0), (False, 10_000)])
+def test_strategy_statistics_taken_inside_the_fused_backward(absgrad, scale2d_stop):
+    """DefaultStrategy's per-step statistics (gsplat DefaultStrategy._update_state) accumulated by the fused projection
+    backward (gsr_project_bwd_adam_ex, gsr_step_extras.stat_*) while the gradient rows and radii are in its registers,
+    against the strategy's own launch after an unfused backward: same grad2d / count / radii accumulators after six
+    steps on two copies of a scene (N not a multiple of 64: the last wave is partial), and no statistics launch."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    S = importlib.import_module("3dgs_monocular_depth_init_amd.strategy")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 3003
+    sc = scenes.make_scene(N, 2, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 96, 64
+    vm, K = scenes.cameras([0, 25, 50, 75], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    calls = []
+    real = S._call
+
+    def run(fuse):
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        fused.fuse_into_backward(fuse)
+        strat = S.DefaultStrategy(absgrad=absgrad, refine_scale2d_stop_iter=scale2d_stop, refine_start_iter=10 ** 6)
+        state = strat.initialize_state(scene_scale=1.0)
+        cfg = runner.RasterConfig(absgrad=absgrad)
+
+        def spy():
+            fn = real()
+            def wrapped(name, *a):
+                calls.append(name)
+                return fn(name, *a)
+            return wrapped
+
+        S._call = spy
+        try:
+            for step in range(6):
+                k = step % 4
+                runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target, step=4000 + step, cfg=cfg,
+                                  strategy=strat, strategy_state=state)
+        finally:
+            S._call = real
+            R.set_backward_optimizer(None)
+        torch.cuda.synchronize()
+        return {k: (None if v is None else v.clone()) for k, v in state.items() if k in ("grad2d", "count", "radii")}
+
+    a = run(True)
+    assert "gsr_strategy_accumulate" not in calls
+    b = run(False)
+    assert calls.count("gsr_strategy_accumulate") == 6
+    assert float(b["count"].sum()) > 1000 and float(b["grad2d"].max()) > 0
+    assert torch.equal(a["count"], b["count"])
+    assert torch.allclose(a["grad2d"], b["grad2d"], rtol=1e-4, atol=1e-6 * float(b["grad2d"].max()))
+    if scale2d_stop > 0:
+        assert torch.equal(a["radii"], b["radii"]) and float(b["radii"].max()) > 0
+    else:
+        assert a["radii"] is None and b["radii"] is None
