@@ -315,7 +315,9 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
       r2b += v2.sh;
     };
     const int64_t o_first = ((int64_t)plane * H + y0) * W + gx;   // this lane's element of the strip's first output row
-    float wm1[11], wm2[11], w11[11], w22[11], w12[11];      // horizontally filtered rows: x, y, xx, yy, xy
+    // horizontally filtered rows: x, y, xx + yy, xy. (The two second moments are only ever used as their sum: B = s1 + s2
+    // + C2 = E[xx] + E[yy] - mu1^2 - mu2^2 + C2 -- four filtered quantities instead of five.)
+    float wm1[11], wm2[11], wss[11], w12[11];
     float nxa, nya, nxb, nyb;
     fetch(0, nxa, nya, nxb, nyb);
     const int rows_in = rows_out + 2 * SSIM_R;
@@ -344,31 +346,27 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
           wm1[sl] = sym11(xs);
           wm2[sl] = sym11(ys);
 #pragma unroll
-          for (int k = 0; k < 11; ++k) t[k] = xs[k] * xs[k];
-          w11[sl] = sym11(t);
-#pragma unroll
-          for (int k = 0; k < 11; ++k) t[k] = ys[k] * ys[k];
-          w22[sl] = sym11(t);
+          for (int k = 0; k < 11; ++k) t[k] = fmaf(xs[k], xs[k], ys[k] * ys[k]);
+          wss[sl] = sym11(t);
 #pragma unroll
           for (int k = 0; k < 11; ++k) t[k] = xs[k] * ys[k];
           w12[sl] = sym11(t);
           if (j >= 2 * SSIM_R) {                            // output row i = j - 10: window rows j-10 .. j
             const int i = j - 2 * SSIM_R, gy = y0 + i;
             const int64_t o_row = o_first + (int64_t)i * W;
-            float o1[11], o2[11], o11[11], o22[11], o12[11];
+            float o1[11], o2[11], oss[11], o12[11];
 #pragma unroll
             for (int k = 0; k < 11; ++k) {                  // slot of input row (j - 10 + k)
               const int q = (sl + 1 + k) % 11;
               o1[k] = wm1[q];
               o2[k] = wm2[q];
-              o11[k] = w11[q];
-              o22[k] = w22[q];
+              oss[k] = wss[q];
               o12[k] = w12[q];
             }
-            const float mu1 = sym11(o1), mu2 = sym11(o2), e11 = sym11(o11), e22 = sym11(o22), e12 = sym11(o12);
+            const float mu1 = sym11(o1), mu2 = sym11(o2), ess = sym11(oss), e12 = sym11(o12);
             if (gx < W) {
-              const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
-              const float A = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B = s1 + s2 + SSIM_C2;
+              const float mm = mu1 * mu1 + mu2 * mu2, s12 = e12 - mu1 * mu2;
+              const float A = mm + SSIM_C1, B = (ess - mm) + SSIM_C2;
               const float Cc = 2.f * mu1 * mu2 + SSIM_C1, D = 2.f * s12 + SSIM_C2;
               // (two v_rcp_f32 instead of four IEEE divisions: 44 of this loop's 278 VALU instructions per row went
               // into the division sequences; A >= C1 and B >= C2 are far from the denormal range)
