@@ -35,7 +35,8 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                   const int32_t *__restrict__ tile_order,
                   const int32_t *__restrict__ pair_ids, float *__restrict__ render_colors,
                   float *__restrict__ render_alphas, int32_t *__restrict__ last_ids,
-                  float4 *__restrict__ zero_rows, int64_t n_zero16) {
+                  float4 *__restrict__ zero_rows, int64_t n_zero16, const float *__restrict__ l1_target,
+                  float l1_scale, double *__restrict__ l1_partials) {
   // staged batches: row r = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | -}.
   // 2 x 2 KB per wave; the workgroup IS one wave, so no barriers: the DMA into buffer (k+1)&1 is
   // issued after the loop over batch k-1 has consumed its last read of that buffer.
@@ -177,6 +178,11 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   }
   TL_STORE(0, tile, e - s);
 
+  // l1_target (gsr_rasterize_fwd_l1, the training step with the plain L1 loss, runner.py:506): the loss is taken while
+  // the finished pixels are still in registers -- sum |render - target| per tile into l1_partials, and `render_colors`
+  // receives d mean|render - target| / d render = sign(render - target) * l1_scale instead of the render (which
+  // nothing else of that step reads): the 75 MB pass of gsr_l1_fwd disappears from the step.
+  float l1_part = 0.f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if ((outside >> q) & 1u) continue;
@@ -186,6 +192,11 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     for (int k = 0; k < CH; ++k) {
       float v = acc[q][k];
       if (backgrounds) v += T[q] * backgrounds[cam * CH + k];
+      if (l1_target) {
+        const float d = v - l1_target[pix * CH + k];
+        l1_part += fabsf(d);
+        v = d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f);
+      }
       out[k] = v;
     }
     render_alphas[pix] = 1.0f - T[q];
@@ -193,6 +204,26 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
     // at that moment), else the end of the tile's list (the backward re-tests alpha >= 1/255 per
     // pair itself, so the exact position of the last contributor is not needed and not tracked)
     if (px[q] != PIX_DONE) last_ids[pix] = last;
+  }
+  if (l1_target) {
+    const float tile_sum = wave_sum(l1_part);
+    if (lane == 0) l1_partials[blockIdx.x] = (double)tile_sum;
+  }
+}
+
+// mean_out[0] = (sum of the per-tile partial sums) * inv_n
+__global__ void __launch_bounds__(1024)
+l1_tiles_finalize_kernel(int n_partials, const double *__restrict__ partials, double inv_n, float *__restrict__ mean_out) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += 1024) acc += partials[i];
+  acc = wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    mean_out[0] = (float)(t * inv_n);
   }
 }
 
@@ -206,11 +237,12 @@ static int launch_fwd(int n_tiles, const float *records, const float *background
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *pair_ids, float *render_colors,
                       float *render_alphas, int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
-                      hipStream_t stream) {
+                      hipStream_t stream, const float *l1_target = nullptr, float l1_scale = 0.f,
+                      double *l1_partials = nullptr) {
   hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), occupancy_pad("GSR_FWD_LDS_PAD"), stream, n_tiles, records,
                      backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
                      pair_ids, render_colors, render_alphas, last_ids, reinterpret_cast<float4 *>(zero_rows),
-                     n_zero_rows * (GSR_GRAD_ROW / 4));
+                     n_zero_rows * (GSR_GRAD_ROW / 4), l1_target, l1_scale, l1_partials);
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
 }
@@ -280,6 +312,37 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
   }
 #undef GSR_FWD_CASE
   return GSR_EINVAL;
+}
+
+// The compositing forward of a training step whose loss is the plain L1 (runner.py:506, ssim_lambda = 0), three
+// channels: `grad_out` [C,H,W,3] receives d mean|render - target| / d render = sign(render - target) / (C H W 3) (what
+// gsr_rasterize_bwd takes as v_render_colors under a root gradient of 1), mean_out[0] the loss; the render itself is
+// not written. l1_partials: n_tiles device doubles (scratch).
+extern "C" int gsr_rasterize_fwd_l1(int C, const float *records, const float *backgrounds, int width,
+                                    int height, int tile_w, int tile_h, const int32_t *tile_offsets,
+                                    const int32_t *tile_order, const int32_t *pair_ids,
+                                    const float *target, float *grad_out, float *render_alphas,
+                                    int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
+                                    double *l1_partials, float *mean_out, void *stream) {
+  GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_fwd_l1: bad sizes");
+  GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
+              "rasterize_fwd_l1: tile grid %dx%d does not match %dx%d image", tile_w, tile_h, width, height);
+  if (C == 0) return GSR_OK;
+  GSR_REQUIRE(tile_offsets && target && grad_out && render_alphas && last_ids && l1_partials && mean_out,
+              "rasterize_fwd_l1: null pointer");
+  GSR_REQUIRE(((uintptr_t)records & 15) == 0, "rasterize_fwd_l1: records must be 16-byte aligned");
+  GSR_REQUIRE(!zero_rows || (n_zero_rows >= 0 && ((uintptr_t)zero_rows & 15) == 0),
+              "rasterize_fwd_l1: zero_rows must be 16-byte aligned");
+  const int n_tiles = C * tile_w * tile_h;
+  const double n = (double)C * height * width * 3.0;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = gsr::launch_fwd<3>(n_tiles, records, backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                                    pair_ids, grad_out, render_alphas, last_ids, zero_rows, n_zero_rows, st, target,
+                                    (float)(1.0 / n), l1_partials);
+  if (rc != GSR_OK) return rc;
+  hipLaunchKernelGGL(gsr::l1_tiles_finalize_kernel, dim3(1), dim3(1024), 0, st, n_tiles, l1_partials, 1.0 / n, mean_out);
+  GSR_CHECK_LAUNCH("rasterize_fwd_l1 (finalize)");
+  return GSR_OK;
 }
 
 #ifdef GSR_RASTER_TIMELINE

@@ -591,10 +591,15 @@ def _isect_bucketed(means2d, radii, depths, tile_w, tile_h, capacity: Optional[i
 # --------------------------------------------------------------------------- #
 # A6 / A7: compositing
 # --------------------------------------------------------------------------- #
+_L1_PARTIALS: Dict[Tuple[int, int], Tensor] = {}     # (device, tiles) -> per-tile partial sums of gsr_rasterize_fwd_l1
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order,
-                pair_ids, records, cfg):
+                pair_ids, records, cfg, l1_target=None):
+        """l1_target ([C,H,W,3], the step's target image): the FIRST output is then the scalar mean |render - target|
+        instead of the render (gsr_rasterize_fwd_l1: the L1 loss taken inside the compositing forward)."""
         width, height, tile_w, tile_h, CH, absgrad = cfg
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
@@ -613,9 +618,23 @@ class _Rasterize(torch.autograd.Function):
         rows = None
         if CLEAR_ROWS_IN_FORWARD and C * N > 0 and C * tile_w * tile_h > 0 and any(ctx.needs_input_grad[:4]):
             rows = torch.empty(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
-        call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
-             tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
-             ptr(render_alphas), ptr(last_ids), ptr(rows), C * N, _stream())
+        ctx.l1_grad = None
+        if l1_target is not None:
+            assert CH == 3 and tuple(l1_target.shape) == (C, height, width, 3) and l1_target.is_contiguous()
+            n_tiles = C * tile_w * tile_h
+            part = _L1_PARTIALS.get((dev.index, n_tiles))
+            if part is None:
+                part = _L1_PARTIALS[(dev.index, n_tiles)] = torch.empty(max(n_tiles, 1), dtype=torch.float64, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            call("gsr_rasterize_fwd_l1", C, ptr(records), ptr(backgrounds), width, height, tile_w, tile_h,
+                 ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(l1_target), ptr(render_colors),
+                 ptr(render_alphas), ptr(last_ids), ptr(rows), C * N, ptr(part), ptr(loss), _stream())
+            ctx.l1_grad = render_colors          # (holds d loss / d render, not the render)
+            render_colors = loss
+        else:
+            call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
+                 tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
+                 ptr(render_alphas), ptr(last_ids), ptr(rows), C * N, _stream())
         ctx.rows = rows
         ctx.cfg = cfg
         ctx.shape = (C, N, color_stride, per_cam)
@@ -634,6 +653,15 @@ class _Rasterize(torch.autograd.Function):
          records) = ctx.saved_tensors
         C, N, color_stride, per_cam = ctx.shape
         dev = means2d.device
+        if ctx.l1_grad is not None:          # first output was the L1 loss: its upstream gradient scales the stored image
+            from .losses import _UNIT
+            unit = _UNIT.get(dev)
+            up = v_render_colors
+            v_render_colors = ctx.l1_grad
+            if up is None:
+                v_render_colors = None
+            elif not (unit is not None and up.data_ptr() == unit.data_ptr()):
+                v_render_colors = v_render_colors * up.to(v_render_colors.dtype)
         if v_render_colors is None:
             v_render_colors = torch.zeros(C, height, width, CH, dtype=torch.float32, device=dev)
         v_render_colors = _f32c(v_render_colors)
@@ -660,7 +688,7 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             T_final = 1.0 - render_alphas
             v_bg = (v_render_colors * T_final).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -696,6 +724,7 @@ def rasterization(
     _campos: Optional[Tensor] = None,
     _tight_tiles: bool = False,
     _isect_ids: bool = True,
+    _l1_target: Optional[Tensor] = None,
     **unsupported,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
@@ -827,6 +856,15 @@ def rasterization(
         backgrounds = backgrounds.contiguous()
 
     rcfg = (int(width), int(height), tile_w, tile_h, CH, bool(absgrad))
+    l1_target = None
+    if _l1_target is not None:
+        # (private, runner.train_step: the step's plain L1 loss inside the compositing forward; `render_colors` is then
+        # returned as None and meta["l1_loss"] holds mean |render - target|)
+        if CH != 3 or render_mode != "RGB":
+            raise ValueError("_l1_target: three colour channels, render_mode RGB")
+        l1_target = _f32c(_l1_target)
+        if tuple(l1_target.shape) != (C, int(height), int(width), 3):
+            raise ValueError(f"_l1_target: expected {(C, int(height), int(width), 3)}, got {tuple(l1_target.shape)}")
     # Tile lists + compositing. When the bucketed builder applies and a previous frame
     # told us how many intersections to expect, nothing here waits for the GPU until the
     # compositing forward has been queued (see _IsectState).
@@ -838,7 +876,7 @@ def rasterization(
             opacities=opac.detach().contiguous(), tight=bool(_tight_tiles), want_keys=bool(_isect_ids))
         render_colors, render_alphas, _last = _Rasterize.apply(
             means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, pair_ids,
-            records if use_sh else None, rcfg)
+            records if use_sh else None, rcfg, l1_target)
         if not isinstance(tpg, _PendingIsect):
             break
         n_isects, overflowed = tpg.resolve()
@@ -874,4 +912,7 @@ def rasterization(
         "isect_offsets": tile_offsets[:-1].view(C, tile_h, tile_w),
         "width": width, "height": height, "tile_size": TILE, "n_cameras": C,
     }
+    if l1_target is not None:
+        meta["l1_loss"] = render_colors          # (the first output of _Rasterize in this mode)
+        render_colors = None
     return render_colors, render_alphas, meta

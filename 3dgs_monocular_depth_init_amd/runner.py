@@ -140,6 +140,11 @@ def rasterize_splats(
     return render_colors, render_alphas, info
 
 
+# The plain L1 loss inside the compositing forward (gsr_rasterize_fwd_l1) when a step's configuration allows it
+# (train_step); False keeps the separate loss launches (A/B, tests).
+L1_IN_FORWARD = True
+
+
 def train_step(
     splats,
     optimizers: Optional[Dict[str, torch.optim.Optimizer]],
@@ -169,11 +174,18 @@ def train_step(
     height, width = pixels.shape[1:3]
     sh_degree_to_use = min(step // max(cfg.sh_degree_interval, 1), cfg.sh_degree)   # runner.py:464
     depth_loss = depth_points is not None
+    # the plain L1 loss (runner.py:506 with ssim_lambda = 0) is taken inside the compositing forward when nothing else
+    # reads the render: no 75 MB loss pass of its own (gsr_rasterize_fwd_l1)
+    l1_in_forward = (L1_IN_FORWARD and ssim_lambda <= 0.0 and not depth_loss and not random_background and masks is None
+                     and pixels.dtype == torch.float32 and pixels.shape[-1] == 3 and pixels.is_cuda)
     renders, alphas, info = rasterize_splats(
         splats, camtoworlds, Ks, width, height, cfg, masks=masks,
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
-        render_mode="RGB+ED" if depth_loss else "RGB")                   # runner.py:476
-    if renders.shape[-1] == 4:                                           # runner.py:479-482
+        render_mode="RGB+ED" if depth_loss else "RGB",                   # runner.py:476
+        **({"_l1_target": pixels} if l1_in_forward else {}))
+    if renders is None:                                                  # (l1_in_forward)
+        colors, depths = None, None
+    elif renders.shape[-1] == 4:                                         # runner.py:479-482
         colors, depths = renders[..., 0:3], renders[..., 3:4]
     else:
         colors, depths = renders, None                                   # (no slice node in the RGB case)
@@ -182,7 +194,9 @@ def train_step(
         colors = colors + background * (1.0 - alphas)
     if strategy is not None:
         strategy.step_pre_backward(splats, optimizers, strategy_state, step, info)   # runner.py:497
-    if ssim_lambda > 0.0:
+    if l1_in_forward:
+        loss = info["l1_loss"]
+    elif ssim_lambda > 0.0:
         from .losses import l1_ssim_loss                                 # runner.py:506-510 fused
         loss = l1_ssim_loss(colors, pixels, ssim_lambda)
     else:

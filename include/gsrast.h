@@ -300,6 +300,16 @@ int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrou
                       float *zero_rows /* NULL, or the [n_zero_rows, 16] grad_rows buffer the backward of
                                           this render will accumulate into: cleared here, on the side */,
                       int64_t n_zero_rows, void *stream);
+/* gsr_rasterize_fwd for a training step whose loss is the plain L1 (F.l1_loss(colors, pixels), runner.py:506, three
+ * channels): the loss is taken while the finished pixels are in registers. grad_out [C,H,W,3] receives
+ * d mean|render - target| / d render = sign(render - target) / (C H W 3) -- what gsr_rasterize_bwd takes as
+ * v_render_colors under a root gradient of 1 -- and mean_out[0] (device) the loss; the render itself is not written.
+ * l1_partials: C*tile_h*tile_w device doubles (scratch). Replaces gsr_rasterize_fwd + gsr_l1_fwd of that step. */
+int gsr_rasterize_fwd_l1(int C, const float *records, const float *backgrounds, int width, int height,
+                         int tile_w, int tile_h, const int32_t *tile_offsets, const int32_t *tile_order,
+                         const int32_t *pair_ids, const float *target /* [C,H,W,3] */, float *grad_out,
+                         float *render_alphas, int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
+                         double *l1_partials, float *mean_out, void *stream);
 int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *tile_offsets,
                       const int32_t *tile_order, const int32_t *pair_ids,

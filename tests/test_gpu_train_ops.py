@@ -728,3 +728,68 @@ def test_strategy_statistics_taken_inside_the_fused_backward(absgrad, scale2d_st
         assert torch.equal(a["radii"], b["radii"]) and float(b["radii"].max()) > 0
     else:
         assert a["radii"] is None and b["radii"] is None
+
+
+@pytest.mark.parametrize("with_background", [False, True])
+def test_l1_loss_inside_the_compositing_forward_equals_separate_loss_launches(with_background):
+    """gsr_rasterize_fwd_l1 (runner.train_step with the plain L1 loss): the loss value and d loss / d render are produced
+    by the compositing forward's epilogue instead of gsr_l1_fwd. Same loss, same parameters and Adam moments after three
+    steps as with the separate launches; an image whose size is not a multiple of the tile (partial tiles), and the
+    kernel-level call with a background."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 3001
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 100, 70                                   # 7 x 5 tiles, the last column / row partial
+    vm, K = scenes.cameras([0, 30, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    if with_background:
+        # kernel level: rasterization(_l1_target=...) against rasterization() + l1_loss, white-ish background
+        splats, _ = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        L = importlib.import_module("3dgs_monocular_depth_init_amd.losses")
+        bg = torch.tensor([[0.9, 0.8, 0.7]], device="cuda")
+        grads = []
+        for fused in (True, False):
+            for p in splats.values():
+                p.grad = None
+            kw = {"_l1_target": target} if fused else {}
+            rc, ra, info = runner.rasterize_splats(splats, c2w[:1], K[:1], W, H, sh_degree=3, backgrounds=bg, **kw)
+            loss = info["l1_loss"] if fused else L.l1_loss(rc, target)
+            assert (rc is None) == fused
+            loss.backward()
+            grads.append((float(loss.detach()), {k: p.grad.clone() for k, p in splats.items()}))
+        assert abs(grads[0][0] - grads[1][0]) < 1e-6
+        for k in grads[0][1]:
+            a, b = grads[0][1][k], grads[1][1][k]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, k
+        return
+
+    def run(fused_l1):
+        runner.L1_IN_FORWARD = fused_l1
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        fused.fuse_into_backward(True)
+        calls, real = [], R.call
+        R.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            losses = [float(runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target, step=5000 + k)[0]) for k in range(3)]
+        finally:
+            R.call = real
+            runner.L1_IN_FORWARD = True
+            R.set_backward_optimizer(None)
+        assert ("gsr_rasterize_fwd_l1" in calls) == fused_l1 and ("gsr_rasterize_fwd" in calls) != fused_l1
+        return losses, {k: p.detach().clone() for k, p in splats.items()}, {k: fused[k].state[splats[k]]["exp_avg_sq"].clone() for k in splats}
+
+    la, pa, va = run(True)
+    lb, pb, vb = run(False)
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 1e-6
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * float(pb[k].abs().max()) + 1e-8, k
+        assert float((va[k] - vb[k]).abs().max()) <= 1e-4 * float(vb[k].abs().max()) + 1e-14, k
