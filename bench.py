@@ -493,7 +493,7 @@ def main():
                 "workload": ("c4: 1M-Gaussian seeded scene S(1e6,seed 0), 100 synthetic cameras "
                              "1920x1080 f=1200, 1 view/rank/step, SH degree 3, tight tile lists "
                              "(runner.rasterize_splats default: pairs whose alpha >= 1/255 ellipse misses the tile are not listed), "
-                             + ("L1 loss" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
+                             + ("L1 loss (taken inside the compositing forward, gsr_rasterize_fwd_l1)" if args.ssim_lambda == 0 else f"L1 + {args.ssim_lambda} SSIM loss")
                              + ", full backward"
                              + ("" if args.no_optimizer else " + Adam on all 59N parameters")
                              + ((", RCCL all-gather of 9N fp32 view-space gradient rows (equivalent to the gradient all-reduce)" if args.sync == "gather"
