@@ -127,7 +127,8 @@ def rasterize_splats(
     rasterize_mode = "antialiased" if cfg.antialiased else "classic"
     # runner.py:324-325 (exp / sigmoid) run inside the projection kernels, and
     # runner.py:347 `torch.linalg.inv(camtoworlds)` is one small launch
-    viewmats, campos = inverse4x4(camtoworlds, translation_of="input")   # + camera positions, one launch
+    pre = kwargs.pop("_viewmats_campos", None)      # (runner.train: the frame's inverse, taken once when it became resident)
+    viewmats, campos = pre if pre is not None else inverse4x4(camtoworlds, translation_of="input")   # + camera positions, one launch
     render_colors, render_alphas, info = rasterization(
         means=means, quats=quats, scales=splats["scales"], opacities=splats["opacities"],
         colors=colors, viewmats=viewmats, Ks=Ks, width=width, height=height,
@@ -167,6 +168,8 @@ def train_step(
     scene_scale: float = 1.0,
     before_update=None,         # callable(loss, info): runs after backward, before strategy / optimizer
                                 # (the reference's checkpoint point, runner.py:592-637); suspends the fusion
+    viewmats_campos=None,       # (viewmats [C,4,4], camera positions [C,3]) = inverse4x4(camtoworlds, "input") when the
+                                # caller already holds them (fixed cameras): saves the step's 4x4-inverse launch
 ) -> Tuple[Tensor, Dict]:
     """One iteration of Runner.train's body (runner.py:464-547, 639-689):
     SH-degree schedule, render, L1 (+ optional SSIM term), backward,
@@ -182,7 +185,8 @@ def train_step(
         splats, camtoworlds, Ks, width, height, cfg, masks=masks,
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         render_mode="RGB+ED" if depth_loss else "RGB",                   # runner.py:476
-        **({"_l1_target": pixels} if l1_in_forward else {}))
+        **({"_l1_target": pixels} if l1_in_forward else {}),
+        **({"_viewmats_campos": viewmats_campos} if viewmats_campos is not None else {}))
     if renders is None:                                                  # (l1_in_forward)
         colors, depths = None, None
     elif renders.shape[-1] == 4:                                         # runner.py:479-482
@@ -459,7 +463,9 @@ def train(
         # launch would re-pack it on every step)
         e = {k: d[k].to(device)[None].contiguous() for k in ("camtoworld", "K", "mask", "points", "depths") if k in d}
         e["pixels"] = (d["image"].to(device)[None].float() / 255.0).contiguous()
-        size = sum(t.numel() * t.element_size() for t in e.values())
+        if e["camtoworld"].is_cuda:      # fixed cameras (no pose optimisation here): the inverse once per frame, not per step
+            e["viewmats_campos"] = _R.inverse4x4(e["camtoworld"], translation_of="input")
+        size = sum(t.numel() * t.element_size() for t in e.values() if isinstance(t, Tensor))
         if resident_bytes + size <= device_cache_bytes:
             resident[i] = e
             resident_bytes += size
@@ -521,7 +527,7 @@ def train(
                 splats, opt, c2w, Ks, pixels, step, rc, ssim_lambda=cfg.ssim_lambda, grad_sync=grad_sync,
                 strategy=strategy, strategy_state=strategy_state, opacity_reg=cfg.opacity_reg,
                 scale_reg=cfg.scale_reg, random_background=cfg.random_background, masks=masks,
-                before_update=hook, **extra)
+                before_update=hook, viewmats_campos=(data[0].get("viewmats_campos") if len(data) == 1 else None), **extra)
             for sch in schedulers:                                                     # runner.py:687-689
                 sch.step()
             if step in eval_at and valset is not None:                                 # runner.py:692-694
