@@ -430,3 +430,47 @@ def test_c4_fused_adam_backward_equals_backward_then_adam_step():
             assert float(err.max()) <= 1e-4 * scale, (n, what, float(err.max()), scale)
     for n in ("means", "quats", "shN"):      # and the parameters did move
         assert float((p1[n] - sc[n].cuda()).abs().max()) > 0, n
+
+
+def test_c4_l1_loss_in_the_compositing_forward_at_full_size():
+    """gsr_rasterize_fwd_l1 at c4's size (1 M Gaussians, 1080p: 8 160 tiles, the last row of tiles half outside the
+    image): the loss and d loss / d render it writes against the render of gsr_rasterize_fwd + the L1 loss launches on
+    the same scene -- the loss to 1e-7, the gradient image exactly (sign(render - target) / n wherever |render - target|
+    is not within rounding of zero), and the alphas bit for bit."""
+    Rm = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    losses = importlib.import_module("3dgs_monocular_depth_init_amd.losses")
+    N = 1_000_000
+    sc = scenes.make_scene(N, 0)
+    vm, K = scenes.cameras([3])
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    splats, _ = runner.create_splats_with_optimizers(
+        sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+        quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+    grabbed = {}
+    orig_bwd = Rm._Rasterize.backward
+
+    def spy(ctx, *grads):
+        grabbed["l1_grad"] = None if ctx.l1_grad is None else ctx.l1_grad.clone()
+        return orig_bwd(ctx, *grads)
+
+    with torch.no_grad():
+        rc, ra, _ = runner.rasterize_splats(splats, c2w, K, W, H, runner.RasterConfig(), sh_degree=3)
+    ref_loss = float(losses.l1_loss(rc, target))
+    Rm._Rasterize.backward = staticmethod(spy)
+    try:
+        none, ra2, info = runner.rasterize_splats(splats, c2w, K, W, H, runner.RasterConfig(), sh_degree=3, _l1_target=target)
+        assert none is None
+        info["l1_loss"].backward()
+    finally:
+        Rm._Rasterize.backward = staticmethod(orig_bwd)
+    assert abs(float(info["l1_loss"]) - ref_loss) < 1e-7
+    assert torch.equal(ra2, ra)
+    g = grabbed["l1_grad"]
+    n = float(rc.numel())
+    d = rc - target
+    sure = d.abs() > 1e-6
+    assert torch.equal(g[sure], (torch.sign(d) / n)[sure])
+    assert float(g.abs().max()) <= 1.0 / n * (1 + 1e-6)
+    assert all(torch.isfinite(p.grad).all() for p in splats.values())
