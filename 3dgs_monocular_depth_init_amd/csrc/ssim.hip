@@ -253,7 +253,12 @@ constexpr int SS_COLS = 64;                        // one column per lane
 #ifndef GSR_SS_ROWS
 #define GSR_SS_ROWS 32
 #endif
-constexpr int SS_ROWS = GSR_SS_ROWS;               // output rows per strip (+ 10 halo rows walked)
+#ifndef GSR_SS_ROWS_FWD
+#define GSR_SS_ROWS_FWD 24          // 1080 / 24 = 45 strips: 4 050 forward waves = 4 per SIMD (32 rows: 3 060 = 3 per SIMD;
+                                    // forward 0.060 -> 0.056 ms; the backward, with fewer registers per wave, loses at 24)
+#endif
+constexpr int SS_ROWS = GSR_SS_ROWS;               // output rows per strip of the backward (+ 10 halo rows walked)
+constexpr int SS_ROWS_F = GSR_SS_ROWS_FWD;         // ... of the forward
 constexpr int SS_W = SS_COLS + 2 * SSIM_R;         // 74 inputs per row
 constexpr int SS_WAVES = 4;                        // strips per 256-thread workgroup (independent)
 
@@ -280,15 +285,15 @@ ssim_fwd_sw_kernel(int N, int CH, int H, int W, const float *__restrict__ img1, 
   __shared__ float sRow[SS_WAVES][2][2][SS_W + 2];   // [wave][buffer][image][column]
   __shared__ double red[2][SS_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tiles_x = (W + SS_COLS - 1) / SS_COLS, strips = (H + SS_ROWS - 1) / SS_ROWS;
+  const int tiles_x = (W + SS_COLS - 1) / SS_COLS, strips = (H + SS_ROWS_F - 1) / SS_ROWS_F;
   const int wid = blockIdx.x * SS_WAVES + wave;
   const int plane = blockIdx.y, n = plane / CH, c = plane % CH;
   // per-lane partial sums in fp32 (<= 42 terms of magnitude <= 1 each), fp64 across lanes and workgroups
   float acc_ssim = 0.f, acc_l1 = 0.f;
   if (wid < tiles_x * strips) {
     const int bx = wid % tiles_x, by = wid / tiles_x;
-    const int x0 = bx * SS_COLS, y0 = by * SS_ROWS;
-    const int rows_out = min(SS_ROWS, H - y0);
+    const int x0 = bx * SS_COLS, y0 = by * SS_ROWS_F;
+    const int rows_out = min(SS_ROWS_F, H - y0);
     const int gx = x0 + lane;                               // this lane's output column
     const int gxa = x0 - SSIM_R + lane, gxb = x0 + SS_COLS - SSIM_R + lane;   // columns it stages (b: lanes 0..9)
     const float *p1 = img1 + n * v1.sn + c * v1.sc, *p2 = img2 + n * v2.sn + c * v2.sc;
@@ -649,8 +654,9 @@ extern "C" int gsr_ssim_l1_fwd(int N, int CH, int H, int W, const float *img1,
   hipLaunchKernelGGL(gsr::ssim_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, CH, H, W,
                      img1, v1, img2, v2, valid_only, workspace, dm_mu1, dm_s1, dm_s12);
 #else
-  // (a strip of 64 x 32 pixels per wave: never more partial sums than the 32 x 32 tiles the workspace is sized for)
-  dim3 grid(gsr::ceil_div(gsr::ceil_div(W, gsr::SS_COLS) * gsr::ceil_div(H, gsr::SS_ROWS), gsr::SS_WAVES), N * CH);
+  // (a strip of 64 x 24 pixels per wave, four waves per workgroup: never more partial sums than the 32 x 32 tiles the
+  // workspace is sized for)
+  dim3 grid(gsr::ceil_div(gsr::ceil_div(W, gsr::SS_COLS) * gsr::ceil_div(H, gsr::SS_ROWS_F), gsr::SS_WAVES), N * CH);
   hipLaunchKernelGGL(gsr::ssim_fwd_sw_kernel, grid, dim3(64 * gsr::SS_WAVES), 0, (hipStream_t)stream, N, CH, H, W,
                      img1, v1, img2, v2, valid_only, workspace, dm_mu1, dm_s1, dm_s12);
 #endif
