@@ -38,8 +38,10 @@ SIGNATURES = {
     "gsr_pair_masks": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p],
     "gsr_pack_records": [_i, _i, _i, _p, _p, _p, _i, _p, _i, _p, _p],
     "gsr_rasterize_fwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
+    "gsr_rasterize_fwd_planar": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i64, _p],
     "gsr_rasterize_fwd_l1": [_i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p],
     "gsr_rasterize_bwd": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "gsr_rasterize_bwd_planar": [_i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
 }
 SIGNATURES["gsr_ssim_workspace_doubles"] = [_i, _i, _i, _i]
 SIGNATURES["gsr_ssim_l1_fwd"] = [_i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _f, _p, _p, _p, _p]

@@ -51,7 +51,7 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
                   const int32_t *__restrict__ pair_ids,
                   const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
                   const float *__restrict__ v_render_colors,
-                  const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows) {
+                  const float *__restrict__ v_render_alphas, float *__restrict__ grad_rows, int planar) {
   // staged batches: chunk 0 = {mx, my, ha, bb}, 1 = {hc, opacity, col0, col1}, 2 = {col2, col3, col4, -}
   // of the batch's r-th Gaussian (r = 0 is the LAST list position of the batch)
   __shared__ __attribute__((aligned(16))) float4 sRec[2][3][RBATCH];   // [buffer][16-byte chunk][Gaussian]
@@ -113,7 +113,8 @@ raster_bwd_kernel(int n_tiles, const float *__restrict__ records,
       T[q] = 1.0f - render_alphas[pix];
       float kk = v_render_alphas ? v_render_alphas[pix] : 0.f;
 #pragma unroll
-      for (int k = 0; k < CH; ++k) vout[q][k] = v_render_colors[pix * CH + k];
+      for (int k = 0; k < CH; ++k)      // [C,H,W,CH], or planes [C,CH,H,W] (gsr_rasterize_bwd_planar)
+        vout[q][k] = planar ? v_render_colors[pix + ((int64_t)cam * (CH - 1) + k) * height * width] : v_render_colors[pix * CH + k];
       if (backgrounds) {
 #pragma unroll
         for (int k = 0; k < CH; ++k) kk -= backgrounds[cam * CH + k] * vout[q][k];
@@ -401,7 +402,7 @@ static int launch_bwd(int n_tiles, const float *records, const float *background
                       const int32_t *tile_order, const int32_t *pair_ids,
                       const float *render_alphas, const int32_t *last_ids,
                       const float *v_render_colors, const float *v_render_alphas, int absgrad,
-                      float *grad_rows, hipStream_t stream) {
+                      float *grad_rows, hipStream_t stream, int planar) {
   const unsigned pad = (unsigned)gsr_knob_int("GSR_BWD_LDS_PAD", 0);   // experiment knob: see raster_fwd.hip (0 in the product build)
   // experiment knob (timing only, wrong gradients): launch just the GSR_BWD_TILE_LIMIT longest tiles, or (negative)
   // skip the -limit longest -- how much of the launch is the under-occupied tail of its 8160 / 6144-slot schedule?
@@ -417,12 +418,12 @@ static int launch_bwd(int n_tiles, const float *records, const float *background
     hipLaunchKernelGGL((raster_bwd_kernel<CH, true>), dim3(n_tiles), dim3(64), pad, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
                        tile_order, pair_ids, render_alphas, last_ids, v_render_colors,
-                       v_render_alphas, grad_rows);
+                       v_render_alphas, grad_rows, planar);
   else
     hipLaunchKernelGGL((raster_bwd_kernel<CH, false>), dim3(n_tiles), dim3(64), pad, stream, n_tiles,
                        records, backgrounds, width, height, tile_w, tile_h, tile_offsets,
                        tile_order, pair_ids, render_alphas, last_ids, v_render_colors,
-                       v_render_alphas, grad_rows);
+                       v_render_alphas, grad_rows, planar);
   GSR_CHECK_LAUNCH("rasterize_bwd");
   return GSR_OK;
 }
@@ -438,13 +439,13 @@ extern "C" int gsr_debug_tree_reduce8(const float *in, float *out, int32_t *idx_
   return GSR_OK;
 }
 
-extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds,
-                                 int width, int height, int tile_w, int tile_h,
-                                 const int32_t *tile_offsets, const int32_t *tile_order,
-                                 const int32_t *pair_ids, const float *render_alphas,
-                                 const int32_t *last_ids, const float *v_render_colors,
-                                 const float *v_render_alphas, int absgrad, float *grad_rows,
-                                 void *stream) {
+static int rasterize_bwd_impl(int C, int CH, const float *records, const float *backgrounds,
+                              int width, int height, int tile_w, int tile_h,
+                              const int32_t *tile_offsets, const int32_t *tile_order,
+                              const int32_t *pair_ids, const float *render_alphas,
+                              const int32_t *last_ids, const float *v_render_colors,
+                              const float *v_render_alphas, int absgrad, float *grad_rows,
+                              int planar, void *stream) {
   GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_bwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
               "rasterize_bwd: tile grid does not match image");
@@ -458,7 +459,7 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
   case K:                                                                                       \
     return gsr::launch_bwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
                               tile_offsets, tile_order, pair_ids, render_alphas, last_ids,      \
-                              v_render_colors, v_render_alphas, absgrad, grad_rows, st);
+                              v_render_colors, v_render_alphas, absgrad, grad_rows, st, planar);
   switch (CH) {
     GSR_BWD_CASE(1)
     GSR_BWD_CASE(2)
@@ -468,6 +469,30 @@ extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const floa
   }
 #undef GSR_BWD_CASE
   return GSR_EINVAL;
+}
+
+extern "C" int gsr_rasterize_bwd(int C, int CH, const float *records, const float *backgrounds,
+                                 int width, int height, int tile_w, int tile_h,
+                                 const int32_t *tile_offsets, const int32_t *tile_order,
+                                 const int32_t *pair_ids, const float *render_alphas,
+                                 const int32_t *last_ids, const float *v_render_colors,
+                                 const float *v_render_alphas, int absgrad, float *grad_rows,
+                                 void *stream) {
+  return rasterize_bwd_impl(C, CH, records, backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                            pair_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, absgrad, grad_rows, 0,
+                            stream);
+}
+// The same with v_render_colors laid out [C,CH,H,W] (the gradient of a render produced by gsr_rasterize_fwd_planar).
+extern "C" int gsr_rasterize_bwd_planar(int C, int CH, const float *records, const float *backgrounds,
+                                        int width, int height, int tile_w, int tile_h,
+                                        const int32_t *tile_offsets, const int32_t *tile_order,
+                                        const int32_t *pair_ids, const float *render_alphas,
+                                        const int32_t *last_ids, const float *v_render_colors,
+                                        const float *v_render_alphas, int absgrad, float *grad_rows,
+                                        void *stream) {
+  return rasterize_bwd_impl(C, CH, records, backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                            pair_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, absgrad, grad_rows, 1,
+                            stream);
 }
 
 #ifdef GSR_BWD_COUNT_EMPTY

@@ -36,7 +36,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
                   const int32_t *__restrict__ pair_ids, float *__restrict__ render_colors,
                   float *__restrict__ render_alphas, int32_t *__restrict__ last_ids,
                   float4 *__restrict__ zero_rows, int64_t n_zero16, const float *__restrict__ l1_target,
-                  float l1_scale, double *__restrict__ l1_partials) {
+                  float l1_scale, double *__restrict__ l1_partials, int planar) {
   // staged batches: row r = {mx, my, ha, bb | hc, opacity, col0, col1 | col2, col3, col4, - | -}.
   // 2 x 2 KB per wave; the workgroup IS one wave, so no barriers: the DMA into buffer (k+1)&1 is
   // issued after the loop over batch k-1 has consumed its last read of that buffer.
@@ -187,7 +187,10 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
   for (int q = 0; q < 4; ++q) {
     if ((outside >> q) & 1u) continue;
     const int64_t pix = pix_of(q);
-    float *out = render_colors + pix * CH;
+    // render_colors is [C,H,W,CH], or (planar: what the SSIM kernels read three times faster) [C,CH,H,W]
+    const int64_t hw = (int64_t)height * width;
+    float *out = planar ? render_colors + (int64_t)cam * (CH - 1) * hw + pix : render_colors + pix * CH;
+    const int64_t kstride = planar ? hw : 1;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       float v = acc[q][k];
@@ -197,7 +200,7 @@ raster_fwd_kernel(int n_tiles, const float *__restrict__ records,
         l1_part += fabsf(d);
         v = d > 0.f ? l1_scale : (d < 0.f ? -l1_scale : 0.f);
       }
-      out[k] = v;
+      out[k * kstride] = v;
     }
     render_alphas[pix] = 1.0f - T[q];
     // list position after which nothing is blended into this pixel: where it terminated (stored
@@ -238,11 +241,11 @@ static int launch_fwd(int n_tiles, const float *records, const float *background
                       const int32_t *tile_order, const int32_t *pair_ids, float *render_colors,
                       float *render_alphas, int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
                       hipStream_t stream, const float *l1_target = nullptr, float l1_scale = 0.f,
-                      double *l1_partials = nullptr) {
+                      double *l1_partials = nullptr, int planar = 0) {
   hipLaunchKernelGGL(raster_fwd_kernel<CH>, dim3(n_tiles), dim3(64), occupancy_pad("GSR_FWD_LDS_PAD"), stream, n_tiles, records,
                      backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
                      pair_ids, render_colors, render_alphas, last_ids, reinterpret_cast<float4 *>(zero_rows),
-                     n_zero_rows * (GSR_GRAD_ROW / 4), l1_target, l1_scale, l1_partials);
+                     n_zero_rows * (GSR_GRAD_ROW / 4), l1_target, l1_scale, l1_partials, planar);
   GSR_CHECK_LAUNCH("rasterize_fwd");
   return GSR_OK;
 }
@@ -279,12 +282,12 @@ extern "C" int gsr_pack_records(int C, int N, int CH, const float *means2d, cons
   return GSR_OK;
 }
 
-extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds,
-                                 int width, int height, int tile_w, int tile_h,
-                                 const int32_t *tile_offsets, const int32_t *tile_order,
-                                 const int32_t *pair_ids, float *render_colors,
-                                 float *render_alphas, int32_t *last_ids, float *zero_rows,
-                                 int64_t n_zero_rows, void *stream) {
+static int rasterize_fwd_impl(int C, int CH, const float *records, const float *backgrounds,
+                              int width, int height, int tile_w, int tile_h,
+                              const int32_t *tile_offsets, const int32_t *tile_order,
+                              const int32_t *pair_ids, float *render_colors,
+                              float *render_alphas, int32_t *last_ids, float *zero_rows,
+                              int64_t n_zero_rows, int planar, void *stream) {
   GSR_REQUIRE(C >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   GSR_REQUIRE(tile_w == gsr::ceil_div(width, GSR_TILE) && tile_h == gsr::ceil_div(height, GSR_TILE),
               "rasterize_fwd: tile grid %dx%d does not match %dx%d image", tile_w, tile_h, width,
@@ -302,7 +305,7 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
   case K:                                                                                       \
     return gsr::launch_fwd<K>(n_tiles, records, backgrounds, width, height, tile_w, tile_h,     \
                               tile_offsets, tile_order, pair_ids, render_colors,                \
-                              render_alphas, last_ids, zero_rows, n_zero_rows, st);
+                              render_alphas, last_ids, zero_rows, n_zero_rows, st, nullptr, 0.f, nullptr, planar);
   switch (CH) {
     GSR_FWD_CASE(1)
     GSR_FWD_CASE(2)
@@ -312,6 +315,27 @@ extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const floa
   }
 #undef GSR_FWD_CASE
   return GSR_EINVAL;
+}
+
+extern "C" int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrounds,
+                                 int width, int height, int tile_w, int tile_h,
+                                 const int32_t *tile_offsets, const int32_t *tile_order,
+                                 const int32_t *pair_ids, float *render_colors,
+                                 float *render_alphas, int32_t *last_ids, float *zero_rows,
+                                 int64_t n_zero_rows, void *stream) {
+  return rasterize_fwd_impl(C, CH, records, backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                            pair_ids, render_colors, render_alphas, last_ids, zero_rows, n_zero_rows, 0, stream);
+}
+// The same with render_colors laid out [C,CH,H,W] (planes) instead of [C,H,W,CH]: what the fused L1 + SSIM loss
+// kernels (gsr_ssim_l1_fwd / _bwd, strides per image) read without the 3x line traffic of channel-interleaved memory.
+extern "C" int gsr_rasterize_fwd_planar(int C, int CH, const float *records, const float *backgrounds,
+                                        int width, int height, int tile_w, int tile_h,
+                                        const int32_t *tile_offsets, const int32_t *tile_order,
+                                        const int32_t *pair_ids, float *render_colors,
+                                        float *render_alphas, int32_t *last_ids, float *zero_rows,
+                                        int64_t n_zero_rows, void *stream) {
+  return rasterize_fwd_impl(C, CH, records, backgrounds, width, height, tile_w, tile_h, tile_offsets, tile_order,
+                            pair_ids, render_colors, render_alphas, last_ids, zero_rows, n_zero_rows, 1, stream);
 }
 
 // The compositing forward of a training step whose loss is the plain L1 (runner.py:506, ssim_lambda = 0), three

@@ -597,9 +597,11 @@ _L1_PARTIALS: Dict[Tuple[int, int], Tensor] = {}     # (device, tiles) -> per-ti
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, tile_offsets, tile_order,
-                pair_ids, records, cfg, l1_target=None):
+                pair_ids, records, cfg, l1_target=None, planar=False):
         """l1_target ([C,H,W,3], the step's target image): the FIRST output is then the scalar mean |render - target|
-        instead of the render (gsr_rasterize_fwd_l1: the L1 loss taken inside the compositing forward)."""
+        instead of the render (gsr_rasterize_fwd_l1: the L1 loss taken inside the compositing forward).
+        planar: the render is stored in planes ([C,CH,H,W] memory) and returned as its [C,H,W,CH] view -- the layout the
+        fused L1 + SSIM loss reads / writes a third of the lines in (gsr_rasterize_fwd_planar / _bwd_planar)."""
         width, height, tile_w, tile_h, CH, absgrad = cfg
         C, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
@@ -610,7 +612,9 @@ class _Rasterize(torch.autograd.Function):
             records = torch.empty(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
             call("gsr_pack_records", C, N, CH, ptr(means2d), ptr(conics), ptr(colors), color_stride,
                  ptr(opacities), per_cam, ptr(records), _stream())
-        render_colors = torch.empty(C, height, width, CH, dtype=torch.float32, device=dev)
+        planar = bool(planar) and l1_target is None
+        render_colors = (torch.empty(C, CH, height, width, dtype=torch.float32, device=dev) if planar
+                         else torch.empty(C, height, width, CH, dtype=torch.float32, device=dev))
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         # the backward's gradient rows are cleared by the forward kernel itself, on the side (it is
@@ -632,9 +636,11 @@ class _Rasterize(torch.autograd.Function):
             ctx.l1_grad = render_colors          # (holds d loss / d render, not the render)
             render_colors = loss
         else:
-            call("gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
-                 tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
+            call("gsr_rasterize_fwd_planar" if planar else "gsr_rasterize_fwd", C, CH, ptr(records), ptr(backgrounds),
+                 width, height, tile_w, tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_colors),
                  ptr(render_alphas), ptr(last_ids), ptr(rows), C * N, _stream())
+            if planar:
+                render_colors = render_colors.permute(0, 2, 3, 1)      # [C,H,W,CH] view of the planes
         ctx.rows = rows
         ctx.cfg = cfg
         ctx.shape = (C, N, color_stride, per_cam)
@@ -664,13 +670,18 @@ class _Rasterize(torch.autograd.Function):
                 v_render_colors = v_render_colors * up.to(v_render_colors.dtype)
         if v_render_colors is None:
             v_render_colors = torch.zeros(C, height, width, CH, dtype=torch.float32, device=dev)
-        v_render_colors = _f32c(v_render_colors)
+        # a gradient that arrives in planes (the fused SSIM backward writes it in the layout of the render it was
+        # given) is read as it is; anything else as [C,H,W,CH]
+        v_planar = (v_render_colors.dtype == torch.float32 and not v_render_colors.is_contiguous()
+                    and v_render_colors.permute(0, 3, 1, 2).is_contiguous())
+        if not v_planar:
+            v_render_colors = _f32c(v_render_colors)
         if v_render_alphas is not None:          # None: the kernel takes a null pointer as zeros
             v_render_alphas = _f32c(v_render_alphas)
         rows, ctx.rows = ctx.rows, None      # cleared by the forward; a second backward gets fresh zeros
         if rows is None:
             rows = torch.zeros(C * N, GRAD_ROW, dtype=torch.float32, device=dev)
-        call("gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
+        call("gsr_rasterize_bwd_planar" if v_planar else "gsr_rasterize_bwd", C, CH, ptr(records), ptr(backgrounds), width, height, tile_w,
              tile_h, ptr(tile_offsets), ptr(tile_order), ptr(pair_ids), ptr(render_alphas),
              ptr(last_ids), ptr(v_render_colors), ptr(v_render_alphas), int(absgrad), ptr(rows),
              _stream())
@@ -688,7 +699,7 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             T_final = 1.0 - render_alphas
             v_bg = (v_render_colors * T_final).sum(dim=(1, 2))
-        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -725,6 +736,7 @@ def rasterization(
     _tight_tiles: bool = False,
     _isect_ids: bool = True,
     _l1_target: Optional[Tensor] = None,
+    _planar_render: bool = False,
     **unsupported,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """See module docstring. `packed` only changes gsplat's intermediate
@@ -876,7 +888,7 @@ def rasterization(
             opacities=opac.detach().contiguous(), tight=bool(_tight_tiles), want_keys=bool(_isect_ids))
         render_colors, render_alphas, _last = _Rasterize.apply(
             means2d, conics, feats, opac, backgrounds, tile_offsets, tile_order, pair_ids,
-            records if use_sh else None, rcfg, l1_target)
+            records if use_sh else None, rcfg, l1_target, bool(_planar_render) and render_mode == "RGB")
         if not isinstance(tpg, _PendingIsect):
             break
         n_isects, overflowed = tpg.resolve()

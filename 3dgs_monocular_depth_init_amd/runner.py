@@ -144,6 +144,9 @@ def rasterize_splats(
 # The plain L1 loss inside the compositing forward (gsr_rasterize_fwd_l1) when a step's configuration allows it
 # (train_step); False keeps the separate loss launches (A/B, tests).
 L1_IN_FORWARD = True
+# With the L1 + SSIM loss the render (and the gradient the loss returns) is kept in planes (gsr_rasterize_fwd_planar /
+# _bwd_planar); False keeps [C,H,W,3] memory (A/B, tests).
+PLANAR_RENDER_FOR_SSIM = True
 
 
 def train_step(
@@ -186,6 +189,8 @@ def train_step(
         sh_degree=sh_degree_to_use, near_plane=cfg.near_plane, far_plane=cfg.far_plane,
         render_mode="RGB+ED" if depth_loss else "RGB",                   # runner.py:476
         **({"_l1_target": pixels} if l1_in_forward else {}),
+        # (the fused L1 + SSIM loss reads the render, and writes its gradient, a plane at a time)
+        **({"_planar_render": True} if (PLANAR_RENDER_FOR_SSIM and ssim_lambda > 0.0 and not depth_loss and masks is None) else {}),
         **({"_viewmats_campos": viewmats_campos} if viewmats_campos is not None else {}))
     if renders is None:                                                  # (l1_in_forward)
         colors, depths = None, None
@@ -463,6 +468,8 @@ def train(
         # launch would re-pack it on every step)
         e = {k: d[k].to(device)[None].contiguous() for k in ("camtoworld", "K", "mask", "points", "depths") if k in d}
         e["pixels"] = (d["image"].to(device)[None].float() / 255.0).contiguous()
+        if cfg.ssim_lambda > 0.0:        # planes in memory, [1,H,W,3] in shape: what the SSIM kernels read fastest
+            e["pixels"] = e["pixels"].permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
         if e["camtoworld"].is_cuda:      # fixed cameras (no pose optimisation here): the inverse once per frame, not per step
             e["viewmats_campos"] = _R.inverse4x4(e["camtoworld"], translation_of="input")
         size = sum(t.numel() * t.element_size() for t in e.values() if isinstance(t, Tensor))

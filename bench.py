@@ -232,6 +232,9 @@ def main():
     c2ws_w, Ks_w = torch.cat([c2ws, c2ws[:world]]), torch.cat([Ks, Ks[:world]])
     gen = torch.Generator().manual_seed(2)
     targets = [torch.rand(1, HEIGHT, WIDTH, 3, generator=gen).to(dev) for _ in range(4)]
+    # the same images held in planes ([1,H,W,3] in shape): how runner.train keeps a frame resident when the loss has the
+    # SSIM term (the fused loss kernels read a plane at a time)
+    targets_planar = [t.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1) for t in targets]
     cfg = runner.RasterConfig(sh_degree=SH_DEGREE)
     if not use_dist and not args.no_optimizer and not args.separate_adam:
         # one process, photometric loss only: the projection backward applies the Adam update
@@ -256,7 +259,8 @@ def main():
             sync.set_views(c2ws_w[a:a + world], Ks_w[a:a + world])
         _, info = runner.train_step(
             splats, None if args.no_optimizer else optimizers, c2ws[cam:cam + 1], Ks[cam:cam + 1],
-            targets[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync, ssim_lambda=args.ssim_lambda)
+            (targets_planar if args.ssim_lambda > 0 else targets)[k % 4], step=10_000 + k, cfg=cfg, grad_sync=sync,
+            ssim_lambda=args.ssim_lambda)
         if args.no_optimizer:
             for p in splats.values():
                 p.grad = None
@@ -327,7 +331,7 @@ def main():
     if world == 1 and not use_dist and not args.no_optimizer and args.ssim_lambda == 0.0:
         lam_saved, args.ssim_lambda = args.ssim_lambda, 0.2
         try:
-            dtf, kt_full = timed(3, args.steps, k_next, only={"gsr_ssim_l1_fwd", "gsr_ssim_l1_bwd"})
+            dtf, kt_full = timed(3, args.steps, k_next, only={"gsr_ssim_l1_fwd", "gsr_ssim_l1_bwd"}, every=DOM_EVERY)
         finally:
             args.ssim_lambda = lam_saved
         k_next += 3 + args.steps

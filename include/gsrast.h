@@ -300,6 +300,20 @@ int gsr_rasterize_fwd(int C, int CH, const float *records, const float *backgrou
                       float *zero_rows /* NULL, or the [n_zero_rows, 16] grad_rows buffer the backward of
                                           this render will accumulate into: cleared here, on the side */,
                       int64_t n_zero_rows, void *stream);
+/* gsr_rasterize_fwd / _bwd with the colour image (render_colors, v_render_colors) laid out in planes [C,CH,H,W] instead of
+ * [C,H,W,CH]: the fused L1 + SSIM loss (gsr_ssim_l1_fwd / _bwd take element strides per image) reads and writes a plane
+ * at a time, and on channel-interleaved memory every line is fetched / written by all three planes' workgroups
+ * (forward 0.058 -> 0.052 ms, backward 0.064 -> 0.042 ms at 1080p). Same arguments as the functions they stand in for. */
+int gsr_rasterize_fwd_planar(int C, int CH, const float *records, const float *backgrounds, int width,
+                             int height, int tile_w, int tile_h, const int32_t *tile_offsets,
+                             const int32_t *tile_order, const int32_t *pair_ids, float *render_colors,
+                             float *render_alphas, int32_t *last_ids, float *zero_rows, int64_t n_zero_rows,
+                             void *stream);
+int gsr_rasterize_bwd_planar(int C, int CH, const float *records, const float *backgrounds, int width,
+                             int height, int tile_w, int tile_h, const int32_t *tile_offsets,
+                             const int32_t *tile_order, const int32_t *pair_ids, const float *render_alphas,
+                             const int32_t *last_ids, const float *v_render_colors,
+                             const float *v_render_alphas, int absgrad, float *grad_rows, void *stream);
 /* gsr_rasterize_fwd for a training step whose loss is the plain L1 (F.l1_loss(colors, pixels), runner.py:506, three
  * channels): the loss is taken while the finished pixels are in registers. grad_out [C,H,W,3] receives
  * d mean|render - target| / d render = sign(render - target) / (C H W 3) -- what gsr_rasterize_bwd takes as

@@ -793,3 +793,49 @@ def test_l1_loss_inside_the_compositing_forward_equals_separate_loss_launches(wi
     for k in pa:
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * float(pb[k].abs().max()) + 1e-8, k
         assert float((va[k] - vb[k]).abs().max()) <= 1e-4 * float(vb[k].abs().max()) + 1e-14, k
+
+
+@pytest.mark.parametrize("planar_target", [False, True])
+def test_planar_render_for_the_ssim_loss_equals_interleaved(planar_target):
+    """With the L1 + SSIM loss the compositing forward stores the render in planes (gsr_rasterize_fwd_planar), the fused
+    loss kernels read / write planes through their stride arguments, and the compositing backward reads the gradient in
+    planes (gsr_rasterize_bwd_planar). Same loss values, parameters and moments after three steps as with [C,H,W,3]
+    memory; the target image in either layout; image size not a multiple of the tile or of the SSIM strips."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 3001
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 100, 70
+    vm, K = scenes.cameras([0, 30, 60], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(1, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+    if planar_target:
+        target = target.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+
+    def run(planar):
+        runner.PLANAR_RENDER_FOR_SSIM = planar
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        fused.fuse_into_backward(True)
+        calls, real = [], R.call
+        R.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            losses = [float(runner.train_step(splats, fused, c2w[k:k + 1], K[k:k + 1], target, step=5000 + k, ssim_lambda=0.2)[0])
+                      for k in range(3)]
+        finally:
+            R.call = real
+            runner.PLANAR_RENDER_FOR_SSIM = True
+            R.set_backward_optimizer(None)
+        assert ("gsr_rasterize_fwd_planar" in calls) == planar and ("gsr_rasterize_bwd_planar" in calls) == planar
+        return losses, {k: p.detach().clone() for k, p in splats.items()}, {k: fused[k].state[splats[k]]["exp_avg_sq"].clone() for k in splats}
+
+    la, pa, va = run(True)
+    lb, pb, vb = run(False)
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 1e-6
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * float(pb[k].abs().max()) + 1e-8, k
+        assert float((va[k] - vb[k]).abs().max()) <= 1e-4 * float(vb[k].abs().max()) + 1e-14, k

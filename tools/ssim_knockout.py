@@ -24,3 +24,17 @@ for name, x, y in (("NHWC memory (the rasterizer's output)", a, b), ("planar NCH
         e1.record()
         torch.cuda.synchronize()
         print(name, "maps written" if train else "no maps", "%.1f us per call (forward + finalize)" % (e0.elapsed_time(e1) * 1e3 / 50))
+
+# forward / backward launches of the fused L1 + SSIM loss on channel-interleaved vs planar memory, events around the C calls
+lib = importlib.import_module("3dgs_monocular_depth_init_amd._lib")
+for name, x, y in (("NHWC memory", a, b), ("planar NCHW memory", ap, bp)):
+    x = x.detach().requires_grad_(True)
+    lib.TIMERS, lib.TIMER_ONLY = {}, {"gsr_ssim_l1_fwd", "gsr_ssim_l1_bwd"}
+    for it in range(30):
+        _, _, loss = L._SsimL1.apply(x, y.detach(), True, True, 0.2)
+        loss.backward()
+        x.grad = None
+    torch.cuda.synchronize()
+    t = lib.kernel_times_ms()
+    lib.TIMERS, lib.TIMER_ONLY = None, None
+    print(name, {k: round(v[1] * 1e3, 1) for k, v in t.items()}, "us per call")
