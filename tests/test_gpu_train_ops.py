@@ -839,3 +839,40 @@ def test_planar_render_for_the_ssim_loss_equals_interleaved(planar_target):
     for k in pa:
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * float(pb[k].abs().max()) + 1e-8, k
         assert float((va[k] - vb[k]).abs().max()) <= 1e-4 * float(vb[k].abs().max()) + 1e-14, k
+
+
+def test_l1_loss_inside_the_compositing_forward_two_cameras():
+    """gsr_rasterize_fwd_l1 with two views per step (BASELINE config c2 renders four): per-tile partial sums over both
+    cameras' tiles, mean over both images; same loss and parameters as the separate loss launches, two steps, through
+    the generic (multi-camera) fused projection backward."""
+    from tests import scenes
+    runner = importlib.import_module("3dgs_monocular_depth_init_amd.runner")
+    D = importlib.import_module("3dgs_monocular_depth_init_amd.distributed")
+    R = importlib.import_module("3dgs_monocular_depth_init_amd.rendering")
+    N = 2500
+    sc = scenes.make_scene(N, 1, box=(1.0, 0.7, 0.4), scale_mean=0.03)
+    W, H = 100, 70
+    vm, K = scenes.cameras([0, 30, 60, 90], width=W, height=H, f=90.0, dist=2.5)
+    c2w, K = torch.linalg.inv(vm).contiguous().cuda(), K.cuda()
+    target = torch.rand(2, H, W, 3, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(fused_l1):
+        runner.L1_IN_FORWARD = fused_l1
+        splats, opts = runner.create_splats_with_optimizers(
+            sc["means"], torch.rand(N, 3, generator=torch.Generator().manual_seed(0)), torch.log(sc["scales"]),
+            quats=sc["quats"], opacities_logit=torch.logit(sc["opacities"]), shN=sc["shN"])
+        fused = D.fuse_optimizers(splats, opts)
+        fused.fuse_into_backward(True)
+        try:
+            losses = [float(runner.train_step(splats, fused, c2w[2 * k:2 * k + 2], K[2 * k:2 * k + 2], target, step=5000 + k)[0])
+                      for k in range(2)]
+        finally:
+            runner.L1_IN_FORWARD = True
+            R.set_backward_optimizer(None)
+        return losses, {k: p.detach().clone() for k, p in splats.items()}
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 1e-6
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * float(pb[k].abs().max()) + 1e-8, k
