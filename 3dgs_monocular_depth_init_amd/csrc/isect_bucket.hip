@@ -518,14 +518,26 @@ __device__ __forceinline__ void tile_order_body(int n, const int32_t *tile_offse
   __syncthreads();
   for (int t = tid; t < n; t += nthreads) atomicAdd(&hist[cls(t)], 1);
   __syncthreads();
-  // exclusive prefix over the classes: thread b adds up the classes before its own (broadcast LDS
-  // reads, all classes in parallel; one thread walking the 256 classes serially was most of this
-  // launch's 8 us)
+  // exclusive prefix over the 256 classes: a scan inside each of the four waves that hold them, then the waves'
+  // totals (every thread adding up the classes before its own took up to 255 LDS reads)
+  __shared__ int32_t wtot[ORD_BUCKETS / 64];
   int run = 0;
-  if (tid < ORD_BUCKETS)
-    for (int b = 0; b < tid; ++b) run += hist[b];
+  if (tid < ORD_BUCKETS) {
+    const int lane = tid & 63, own = hist[tid];
+    int incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wtot[tid >> 6] = incl;
+    run = incl - own;
+  }
   __syncthreads();
-  if (tid < ORD_BUCKETS) hist[tid] = run;
+  if (tid < ORD_BUCKETS) {
+    for (int w = 0; w < (tid >> 6); ++w) run += wtot[w];
+    hist[tid] = run;
+  }
   __syncthreads();
   for (int t = tid; t < n; t += nthreads) tile_order[atomicAdd(&hist[cls(t)], 1)] = t;
 }
